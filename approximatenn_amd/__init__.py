@@ -1,0 +1,9 @@
+"""approximatenn_amd -- MI355X-native (gfx950, HIP) backend for approximateNN's precomp()/query() hot path.
+
+The product is the C-ABI shared library under csrc/ (include/*.h); this package is the thin host-side
+mirror of the reference's interface used by the tests, the bench and multi-GPU hosts.
+"""
+from . import _lib
+from .api import Index, Save, gpu_cleanup, gpu_init, precomp, query
+
+__all__ = ["Index", "Save", "precomp", "query", "gpu_init", "gpu_cleanup", "_lib"]

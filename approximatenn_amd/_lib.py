@@ -1,0 +1,84 @@
+"""Loader for the HIP backend's shared libraries (one per precision, see csrc/Makefile).
+
+The product has no CPU implementation: if the library is missing or there is no HIP device, calls fail
+loudly (ImportError here, "No GPU found." + exit(1) from gpu_init() in the library).
+"""
+import ctypes as C
+import os
+import subprocess
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+_libs = {}
+
+
+class SaveT(C.Structure):
+    """save_t -- include/ann.h (layout of /root/reference/ann.h:8-12)."""
+    _fields_ = [("tries", C.c_int), ("n", C.c_size_t), ("k", C.c_size_t),
+                ("d_short", C.c_size_t), ("d_long", C.c_size_t),
+                ("which_par", C.POINTER(C.POINTER(C.c_size_t))),
+                ("par_maxes", C.POINTER(C.c_size_t)), ("graph", C.POINTER(C.c_size_t)),
+                ("row_means", C.c_void_p), ("bases", C.c_void_p)]
+
+
+def build(verbose=False):
+    """Compile every HIP extension for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "all"]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+
+
+def lib_path(prec):
+    return os.path.join(CSRC, "libapproxnn_hip_%s.so" % prec)
+
+
+def load(prec="f32"):
+    assert prec in ("f32", "f64")
+    if prec in _libs:
+        return _libs[prec]
+    path = lib_path(prec)
+    if not os.path.exists(path):
+        raise ImportError("HIP backend %s is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "or `make -C approximatenn_amd/csrc`" % path)
+    lib = C.CDLL(path)
+    vp, sz, u32p = C.c_void_p, C.c_size_t, C.c_void_p
+    lib.annhip_precision.restype = C.c_char_p
+    lib.annhip_index_create.restype = vp
+    lib.annhip_index_create.argtypes = [C.POINTER(SaveT), vp, C.c_int, sz, sz]
+    lib.annhip_index_destroy.argtypes = [vp]
+    lib.annhip_index_info.argtypes = [vp, C.POINTER(sz * 12)]
+    lib.annhip_index_set_stream.argtypes = [vp, vp]
+    lib.annhip_index_export.argtypes = [vp, C.POINTER(SaveT)]
+    lib.annhip_precomp_index.restype = vp
+    lib.annhip_precomp_index.argtypes = [sz, sz, sz, vp, C.c_int, C.c_int, sz, sz, sz, sz, vp]
+    lib.annhip_query.restype = C.c_long
+    lib.annhip_query.argtypes = [vp, sz, vp, C.c_int, C.c_int, vp, vp]
+    lib.annhip_codes.argtypes = [vp, sz, vp, u32p]
+    lib.annhip_stage1_local.argtypes = [vp, sz, vp, C.c_int, u32p, vp, u32p, u32p]
+    lib.annhip_stage1_finalize.restype = C.c_long
+    lib.annhip_stage1_finalize.argtypes = [vp, sz, vp, u32p, u32p, u32p, vp, u32p]
+    lib.annhip_stage1_rows.argtypes = [vp, sz, vp, C.c_int, u32p, u32p, sz, u32p, vp]
+    lib.annhip_stage2_rows.argtypes = [vp, sz, vp, C.c_int, u32p, vp, u32p, vp]
+    lib.annhip_exact_select.argtypes = [vp, C.c_int, sz, u32p, vp, u32p, u32p, vp]
+    lib.annhip_widen_ids.argtypes = [vp, sz, u32p, vp]
+    lib.annhip_profile.argtypes = [vp, C.c_int]
+    lib.annhip_stats.argtypes = [vp, C.POINTER(C.c_double * 8), C.c_int]
+    lib.annhip_cache_clear.argtypes = []
+    lib.gpu_init.argtypes = []
+    lib.gpu_cleanup.argtypes = []
+    lib.register_cleanup.argtypes = [C.CFUNCTYPE(None)]
+    lib.query_gpu.restype = C.POINTER(sz)
+    lib.query_gpu.argtypes = [C.POINTER(SaveT), vp, sz, vp, C.POINTER(vp)]
+    lib.precomp_gpu.restype = C.POINTER(sz)
+    lib.precomp_gpu.argtypes = [sz, sz, sz, vp, C.c_int, sz, sz, sz, sz, C.POINTER(SaveT), C.POINTER(vp)]
+    _libs[prec] = lib
+    return lib
+
+
+# every symbol include/*.h declares for the backend library (checked by tests/test_abi.py)
+EXPORTED = ["gpu_init", "gpu_cleanup", "register_cleanup", "query_gpu", "precomp_gpu", "annhip_precision",
+            "annhip_index_create", "annhip_index_destroy", "annhip_index_info", "annhip_index_set_stream",
+            "annhip_index_export", "annhip_precomp_index", "annhip_query", "annhip_codes", "annhip_stage1_local",
+            "annhip_stage1_finalize", "annhip_stage1_rows", "annhip_stage2_rows", "annhip_exact_select",
+            "annhip_widen_ids", "annhip_profile", "annhip_stats"]
+DISPATCH_EXPORTED = ["precomp", "query", "free_save"]

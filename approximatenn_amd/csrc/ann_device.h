@@ -1,0 +1,264 @@
+// ann_device.h -- device-side building blocks shared by the query and precomp kernels (gfx950 only).
+//
+// Everything here is exact IEEE arithmetic in the reference's operation order; the library is built
+// with -ffp-contract=off so that no multiply-add is fused.  One library is built per
+// precision: FT is float under -DUSE_FLOAT, double otherwise (/root/reference/ftype.h:3-9).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+#ifdef USE_FLOAT
+typedef float FT;
+typedef u32 UB;      // bit pattern of an FT
+typedef float4 VT;   // one 16-byte chunk
+#define ANN_VEC 4
+#else
+typedef double FT;
+typedef u64 UB;
+typedef double2 VT;
+#define ANN_VEC 2
+#endif
+
+#define ANN_WAVE 64
+#define ANN_ID_NONE 0xFFFFFFFFu
+
+__device__ __forceinline__ UB ft_bits(FT x) { return __builtin_bit_cast(UB, x); }
+__device__ __forceinline__ FT ft_from_bits(UB b) { return __builtin_bit_cast(FT, b); }
+__device__ __forceinline__ FT ft_inf() {
+#ifdef USE_FLOAT
+  return __builtin_bit_cast(float, 0x7F800000u);
+#else
+  return __builtin_bit_cast(double, 0x7FF0000000000000ull);
+#endif
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// number of set bits of a 64-bit ballot below this lane
+__device__ __forceinline__ u32 mask_rank(u64 m) {
+  return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0));
+}
+// LDS traffic between lanes of ONE wave: DS ops of a wave execute in order, so a wave-scope
+// fence (compiler + memory ordering) is all that is needed.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ------------------------------------------------------------------ candidate keys
+// A candidate is (squared distance, point id).  Distances are >= +0, so their bit patterns order like
+// the values; (dist_bits, id) ordered lexicographically is the total order used by the selection path.
+#ifdef USE_FLOAT
+typedef u64 Key;
+__device__ __forceinline__ Key key_make(FT d, u32 id) { return ((u64)ft_bits(d) << 32) | id; }
+__device__ __forceinline__ FT key_dist(Key k) { return ft_from_bits((u32)(k >> 32)); }
+__device__ __forceinline__ u32 key_id(Key k) { return (u32)k; }
+__device__ __forceinline__ bool key_less(Key a, Key b) { return a < b; }
+__device__ __forceinline__ bool key_eq(Key a, Key b) { return a == b; }
+__device__ __forceinline__ Key key_max() { return ~0ull; }
+__device__ __forceinline__ Key key_shfl_xor(Key k, int m) {
+  u32 lo = __shfl_xor((u32)k, m), hi = __shfl_xor((u32)(k >> 32), m);
+  return ((u64)hi << 32) | lo;
+}
+#else
+struct Key {
+  u64 d;
+  u64 i;
+};
+__device__ __forceinline__ Key key_make(FT d, u32 id) { return Key{ft_bits(d), id}; }
+__device__ __forceinline__ FT key_dist(Key k) { return ft_from_bits(k.d); }
+__device__ __forceinline__ u32 key_id(Key k) { return (u32)k.i; }
+__device__ __forceinline__ bool key_less(Key a, Key b) { return a.d < b.d || (a.d == b.d && a.i < b.i); }
+__device__ __forceinline__ bool key_eq(Key a, Key b) { return a.d == b.d && a.i == b.i; }
+__device__ __forceinline__ Key key_max() { return Key{~0ull, ~0ull}; }
+__device__ __forceinline__ Key key_shfl_xor(Key k, int m) {
+  Key o;
+  o.d = ((u64)__shfl_xor((u32)(k.d >> 32), m) << 32) | __shfl_xor((u32)k.d, m);
+  o.i = __shfl_xor((u32)k.i, m);
+  return o;
+}
+#endif
+
+__device__ __forceinline__ Key wave_min_key(Key k) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    Key o = key_shfl_xor(k, m);
+    if (key_less(o, k)) k = o;
+  }
+  return k;
+}
+
+// Select the up-to-`want` smallest DISTINCT keys of buf[0..cnt) (LDS, one wave), ascending, into
+// out[0..m) (LDS, disjoint from buf) and return m.  Identical keys (= the same point reached through
+// several buckets) collapse because every pass only looks at keys strictly above the previous pick.
+__device__ inline int wave_select_smallest(const Key *buf, int cnt, int want, Key *out) {
+  const int lane = lane_id();
+  Key prev = key_max();
+  int m = 0;
+  for (; m < want; m++) {
+    Key best = key_max();
+    for (int i = lane; i < cnt; i += ANN_WAVE) {
+      Key c = buf[i];
+      if ((m == 0 || key_less(prev, c)) && key_less(c, best)) best = c;
+    }
+    best = wave_min_key(best);
+    if (key_eq(best, key_max())) break;
+    if (lane == 0) out[m] = best;
+    prev = best;
+  }
+  wave_lds_sync();
+  return m;
+}
+
+// ------------------------------------------------------------------ row layout for power-of-two d
+// A row of D elements is read by LPR lanes as C chunks of 16 bytes per lane; lane position p reads
+// chunks p, p+LPR, ... so that every load instruction covers whole contiguous 128-byte pieces.
+// Element index z = VEC*(p + LPR*c) + j.  The pairwise tree of compute.cl:160-167 (Q4) pairs z with
+// z + s/2 for s = D, D/2, ..., 2: first chunk c with c + C/2 (in-lane), then lane p with p ^ (LPR/2)
+// (cross-lane), finally j with j + VEC/2 (in-lane).  fp add commutes, so the xor butterfly produces in
+// lane position 0 exactly the value the serial in-place tree leaves in m[0].
+template <int D>
+struct RowLay {
+  static constexpr int CHUNKS = D / ANN_VEC;
+  static constexpr int LPR0 = CHUNKS < 8 ? CHUNKS : 8;
+  static constexpr int LPR = (CHUNKS / 4 > LPR0) ? (CHUNKS / 4 > 64 ? 64 : CHUNKS / 4) : LPR0;
+  static constexpr int C = CHUNKS / LPR;    // chunks per lane
+  static constexpr int RPW = ANN_WAVE / LPR;  // rows per wave pass
+  static_assert(D >= 16 && (D & (D - 1)) == 0, "fast layout needs a power of two >= 16");
+  static_assert(C >= 1 && C <= 4 && C * LPR * ANN_VEC == D, "unsupported row length");
+};
+
+enum { ROW_SQDIFF = 0, ROW_PRODUCT = 1 };
+
+// One row against the lane's slice `a` of the left operand.  MODE ROW_SQDIFF: sum (a-b)^2 (compute.cl:
+// 147-149); ROW_PRODUCT: sum a*b (compute.cl:268-275), with the reference's "+ 0" kept in every tree
+// node because it turns -0 into +0 and the hash reads the raw sign bit (compute.cl:165-166,229).
+// The result is valid in lane position 0 of each LPR-lane group.
+template <int D, int MODE>
+__device__ __forceinline__ FT row_reduce(const VT (&a)[RowLay<D>::C], const VT (&b)[RowLay<D>::C]) {
+  typedef RowLay<D> L;
+  FT e[L::C][ANN_VEC];
+#pragma unroll
+  for (int c = 0; c < L::C; c++) {
+    const FT *pa = reinterpret_cast<const FT *>(&a[c]);
+    const FT *pb = reinterpret_cast<const FT *>(&b[c]);
+#pragma unroll
+    for (int j = 0; j < ANN_VEC; j++) {
+      if (MODE == ROW_SQDIFF) {
+        FT df = pa[j] - pb[j];
+        e[c][j] = df * df;
+      } else {
+        e[c][j] = pa[j] * pb[j];
+      }
+    }
+  }
+  const FT zero = 0;
+#pragma unroll
+  for (int h = L::C / 2; h >= 1; h >>= 1)
+#pragma unroll
+    for (int c = 0; c < h; c++)
+#pragma unroll
+      for (int j = 0; j < ANN_VEC; j++)
+        e[c][j] = (MODE == ROW_PRODUCT) ? e[c][j] + (e[c + h][j] + zero) : e[c][j] + e[c + h][j];
+#pragma unroll
+  for (int m = L::LPR / 2; m >= 1; m >>= 1)
+#pragma unroll
+    for (int j = 0; j < ANN_VEC; j++) {
+      FT o = __shfl_xor(e[0][j], m);
+      e[0][j] = (MODE == ROW_PRODUCT) ? e[0][j] + (o + zero) : e[0][j] + o;
+    }
+#pragma unroll
+  for (int h = ANN_VEC / 2; h >= 1; h >>= 1)
+#pragma unroll
+    for (int j = 0; j < h; j++)
+      e[0][j] = (MODE == ROW_PRODUCT) ? e[0][j] + (e[0][j + h] + zero) : e[0][j] + e[0][j + h];
+  return e[0][0];
+}
+
+// Any d: the whole wave works on one row, staging the d terms in LDS scratch m[d] and running the
+// in-place tree literally (odd s term included).  a = left operand (LDS or global), b = row (global).
+// Returns the sum in every lane.
+template <int MODE>
+__device__ inline FT row_reduce_generic(int d, const FT *a, const FT *b, FT *m) {
+  const int lane = lane_id();
+  const FT zero = 0;
+  for (int z = lane; z < d; z += ANN_WAVE) {
+    if (MODE == ROW_SQDIFF) {
+      FT df = a[z] - b[z];
+      m[z] = df * df;
+    } else {
+      m[z] = a[z] * b[z];
+    }
+  }
+  wave_lds_sync();
+  for (int s = d; s >> 1; s >>= 1) {
+    int h = s >> 1;
+    for (int z = lane; z < h; z += ANN_WAVE) {
+      FT g = ((s & 1) && z == 0) ? m[s - 1] : zero;
+      m[z] = m[z] + (m[z + h] + g);
+    }
+    wave_lds_sync();
+  }
+  FT r = m[0];
+  wave_lds_sync();
+  return r;
+}
+
+// ------------------------------------------------------------------ the reference's "sort" network
+// floor(log2(x)), 0 for x == 0 (algc.c:13-22).
+__host__ __device__ inline int ann_lg(size_t x) {
+  int r = 0;
+  while (x >>= 1) r++;
+  return r;
+}
+// Entries of a row of length L the top-k stage can ever look at: the sorted prefix
+// P = 2^floor(log2 L), the k entries that are output, plus one more id for the duplicate test
+// (compute.cl:212-217).  Rows shorter than 16 get a clipped 16-wide network, keep them whole.
+__host__ __device__ inline size_t ann_need_len(size_t L, size_t k) {
+  if (L < 16) return L;
+  size_t P = (size_t)1 << ann_lg(L);
+  size_t m = (P > k ? P : k) + 1;
+  return m < L ? m : L;
+}
+
+// do_sort (alg.c:137-144) on one row held in LDS or global memory, executed by one workgroup.
+// L is the reference's row length (it clips pairs with ib >= L); only indices < ann_need_len are touched.
+template <typename KP, typename IP>
+__device__ inline void block_sort_net(size_t L, KP key, IP ids) {
+  const int lk = ann_lg(L);
+  const u32 npairs = 8u << (lk > 4 ? lk - 4 : 0);
+  for (int s = 0; s < lk; s++)
+    for (int ss = s; ss >= 0; ss--) {
+      for (u32 pr = threadIdx.x; pr < npairs; pr += blockDim.x) {
+        u32 hi = (pr >> ss) << ss, lo = pr ^ hi;
+        u32 ia = hi << 1 | lo;
+        if (ss == s) lo = (1u << ss) - lo - 1;
+        u32 ib = hi << 1 | 1u << ss | lo;
+        if (ib < L) {
+          FT ka = key[ia], kb = key[ib];
+          if (ka > kb) {  // strict: ties and NaN never swap (compute.cl:198-203)
+            u32 ta = ids[ia], tb = ids[ib];
+            key[ia] = kb, key[ib] = ka;
+            ids[ia] = tb, ids[ib] = ta;
+          }
+        }
+      }
+      __syncthreads();
+    }
+}
+
+// sort_and_uniq (alg.c:224-230): network, kill the first of each adjacent equal-id pair, network.
+// `len` = number of stored entries (>= ann_need_len(L,k)).
+template <typename KP, typename IP>
+__device__ inline void block_topk_stage(size_t L, size_t len, KP key, IP ids) {
+  block_sort_net(L, key, ids);
+  const FT inf = ft_inf();
+  // every y reads ids only and writes its own key: no hazard inside the pass
+  for (size_t y = threadIdx.x; y + 1 < len; y += blockDim.x)
+    if (ids[y] == ids[y + 1]) key[y] = key[y] + inf;
+  __syncthreads();
+  block_sort_net(L, key, ids);
+}

@@ -1,0 +1,469 @@
+// ann_query_kernels.h -- HIP kernels of the query()/det_results hot path (gfx950).
+//
+// What the reference does with ~250 OpenCL launches and a materialised [Q][L1][d] tensor
+// (/root/reference/alg.c:458-519, 303-337) is done here by five kernels:
+//
+//   codes_kernel        y - means, projection onto bases, sign hash            (alg.c:462-492)
+//   stage1_select       candidate ids from the bucket tables, row gather, squared L2 in the exact
+//                       tree order, and selection of the k+1 smallest distinct (dist,id) keys
+//                       -- no sort network, no materialised distances          (alg.c:493-500,308-312)
+//   finalize1           proves the selection equals sort/rdups/sort (no ties between different ids
+//                       among the k+1 best, >= k finite, an +inf inside the sorted prefix) or flags
+//                       the query for the exact path
+//   row_dists           exact path / stage 2: every needed slot's id and distance, in slot order
+//                       (shufcomp alg.c:438-452, supercharge compute.cl:252-263, compdists alg.c:233-242)
+//   exact_select        the reference's network + rdups + network, literally    (alg.c:224-230)
+//
+// Only slots below ann_need_len() are ever produced.
+#pragma once
+#include "ann_device.h"
+
+struct TryInfo {   // one try (= one random projection) of the index
+  const u32 *tab;  // [2^ds][pm] bucket table, ids descending then padding n  (alg.c:261-266)
+  u32 pm;          // par_maxes[t]
+  u32 off;         // first slot of this try's block in the candidate row     (alg.c:484-488,449)
+  u32 end;         // off + (ds+1)*pm
+  u32 magic;       // floor(2^32/pm)+1: slot/pm by multiply-high (exact while slot*pm < 2^32)
+};
+
+struct QParams {
+  const FT *points;  // rows [lo,hi) of the point matrix, row-major, d elements each
+  const TryInfo *tries;
+  const u32 *graph;  // [n][k]
+  const FT *means;   // [d]
+  const FT *bases;   // [T][ds][d]
+  u32 n, lo, hi;
+  int d, k, T, ds;
+  u32 L1, P1, Lc1, L2, Lc2;
+};
+
+#define ANN_S1_CHUNK 1024  // slots whose valid ids one wave stages in LDS at a time
+
+// ------------------------------------------------------------------------------------------ codes
+// One wave per (query q, try t): code[q*T+t] (the reference's WRITE layout; stage 1 reads it back as
+// [i*Q+x]).  D = 0: any d (generic tree through LDS).
+template <int D>
+__global__ __launch_bounds__(256) void codes_kernel(QParams P, int Q, const FT *__restrict__ y,
+                                                    u32 *__restrict__ codes) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = lane_id(), w = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const long item = (long)blockIdx.x * wpb + w;
+  const bool live = item < (long)Q * P.T;
+  const int q = live ? (int)(item / P.T) : 0, t = live ? (int)(item % P.T) : 0;
+  u32 code = 0;
+  if constexpr (D > 0) {
+    typedef RowLay<D> L;
+    const int p = lane % L::LPR, g = lane / L::LPR;
+    VT a[L::C];
+    const VT *yp = reinterpret_cast<const VT *>(y + (size_t)q * D) + p;
+    const VT *mp = reinterpret_cast<const VT *>(P.means) + p;
+#pragma unroll
+    for (int c = 0; c < L::C; c++) {
+      VT yv = yp[c * L::LPR], mv = mp[c * L::LPR];
+      FT *o = reinterpret_cast<FT *>(&a[c]);
+      const FT *py = reinterpret_cast<const FT *>(&yv), *pm = reinterpret_cast<const FT *>(&mv);
+#pragma unroll
+      for (int j = 0; j < ANN_VEC; j++) o[j] = py[j] - pm[j];  // subtract_off, compute.cl:44-49
+    }
+    for (int s0 = 0; s0 < P.ds; s0 += L::RPW) {
+      const int s = s0 + g;
+      const bool act = s < P.ds;
+      const VT *bp = reinterpret_cast<const VT *>(P.bases + ((size_t)t * P.ds + (act ? s : 0)) * D) + p;
+      VT b[L::C];
+#pragma unroll
+      for (int c = 0; c < L::C; c++) b[c] = bp[c * L::LPR];
+      FT v = row_reduce<D, ROW_PRODUCT>(a, b);
+      u32 sign = (u32)(ft_bits(v) >> (sizeof(FT) * 8 - 1));
+      if (act && p == 0 && sign) code |= 1u << (P.ds - 1 - s);  // coord 0 = MSB, compute.cl:223-231
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) code |= __shfl_xor(code, m);
+  } else {
+    const int d = P.d;
+    FT *u = reinterpret_cast<FT *>(smem) + (size_t)w * 2 * d, *m = u + d;
+    for (int z = lane; z < d; z += ANN_WAVE) u[z] = y[(size_t)q * d + z] - P.means[z];
+    wave_lds_sync();
+    for (int s = 0; s < P.ds; s++) {
+      FT v = row_reduce_generic<ROW_PRODUCT>(d, u, P.bases + ((size_t)t * P.ds + s) * d, m);
+      code = code << 1 | (u32)(ft_bits(v) >> (sizeof(FT) * 8 - 1));
+    }
+  }
+  if (live && lane == 0) codes[item] = code;
+}
+
+// id stored in slot j of query x's candidate row (compute_which, compute.cl:238-246; layout SURVEY Q9).
+// `tries`/`qcode` live in LDS.  ti is a cursor the caller may keep between increasing j.
+__device__ __forceinline__ u32 slot_id(const TryInfo *tries, const u32 *qcode, u32 j, int &ti) {
+  while (j >= tries[ti].end) ti++;
+  const TryInfo tr = tries[ti];
+  u32 r = j - tr.off;
+  u32 yy = __umulhi(r, tr.magic);
+  u32 z = r - yy * tr.pm;
+  u32 b = qcode[ti] ^ (yy ? 1u << (yy - 1) : 0u);
+  return tr.tab[(size_t)b * tr.pm + z];
+}
+
+// ---------------------------------------------------------------------------------- stage1_select
+// One workgroup per query; its waves split the first P1 slots of the candidate row.  Per wave:
+//   A) read a chunk of slot ids, keep the valid ones this device owns in an LDS list (ballot compaction);
+//   B) gather those rows (LPR lanes per row, 16-byte chunks, next pass prefetched), squared L2 in the
+//      reference's tree order, keep keys below the running (k+1)-th smallest in an LDS buffer, and shrink
+//      that buffer with wave_select_smallest whenever it fills.
+// The waves' survivors are merged by wave 0.  Output per query: K1 = k+1 ascending distinct keys (padded
+// with (+inf, ANN_ID_NONE)), the number of valid slots (for the +inf test of finalize1) and of gathered rows.
+template <int D>
+__global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, const FT *__restrict__ y,
+                                                            int alias, const u32 *__restrict__ codes,
+                                                            int K1, int cap, FT *__restrict__ cand_dist,
+                                                            u32 *__restrict__ cand_id,
+                                                            u32 *__restrict__ nv_tot,
+                                                            u32 *__restrict__ nv_own) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = lane_id(), w = threadIdx.x >> 6, W = blockDim.x >> 6;
+  const u32 x = blockIdx.x;
+  // ---- LDS carve-up (mirrored by stage1_lds_bytes on the host)
+  unsigned char *sp = smem;
+  Key *kbuf_all = reinterpret_cast<Key *>(sp);           sp += sizeof(Key) * (size_t)W * cap;
+  Key *kout_all = reinterpret_cast<Key *>(sp);           sp += sizeof(Key) * (size_t)W * K1;
+  Key *mbuf = reinterpret_cast<Key *>(sp);               sp += sizeof(Key) * (size_t)W * K1;
+  TryInfo *tries = reinterpret_cast<TryInfo *>(sp);      sp += sizeof(TryInfo) * (size_t)P.T;
+  u32 *list_all = reinterpret_cast<u32 *>(sp);           sp += sizeof(u32) * (size_t)W * ANN_S1_CHUNK;
+  u32 *qcode = reinterpret_cast<u32 *>(sp);              sp += sizeof(u32) * (size_t)P.T;
+  int *mcnt = reinterpret_cast<int *>(sp);               sp += sizeof(int) * (size_t)W;
+  u32 *cnts = reinterpret_cast<u32 *>(sp);               sp += sizeof(u32) * 2;
+  sp = smem + (((sp - smem) + 15) & ~(size_t)15);
+  FT *yq = reinterpret_cast<FT *>(sp);  // generic d only: [d] + W*[d]
+  Key *kbuf = kbuf_all + (size_t)w * cap, *kout = kout_all + (size_t)w * K1;
+  u32 *list = list_all + (size_t)w * ANN_S1_CHUNK;
+
+  for (int i = threadIdx.x; i < P.T; i += blockDim.x) {
+    tries[i] = P.tries[i];
+    qcode[i] = codes[(size_t)i * Q + x];  // Q2: read layout [try][query]
+  }
+  if (threadIdx.x < 2) cnts[threadIdx.x] = 0;
+  if constexpr (D == 0)
+    for (int z = threadIdx.x; z < P.d; z += blockDim.x) yq[z] = y[(size_t)x * P.d + z];
+  __syncthreads();
+
+  // this wave's slice of [0, P1)
+  const u32 per = (((P.P1 + W - 1) / W) + 63u) & ~63u;
+  const u32 s0 = min(P.P1, (u32)w * per), s1 = min(P.P1, s0 + per);
+
+  Key tau = key_max();
+  int kcnt = 0;
+  u32 vtot = 0, vown = 0;
+
+  // the query row, as this lane's slice
+  VT a[D > 0 ? RowLay<(D > 0 ? D : 16)>::C : 1];
+  if constexpr (D > 0) {
+    typedef RowLay<D> L;
+    const VT *yp = reinterpret_cast<const VT *>(y + (size_t)x * D) + (lane % L::LPR);
+#pragma unroll
+    for (int c = 0; c < L::C; c++) a[c] = yp[c * L::LPR];
+  }
+
+  for (u32 c0 = s0; c0 < s1; c0 += ANN_S1_CHUNK) {
+    const u32 c1 = min(s1, c0 + ANN_S1_CHUNK);
+    // ---- A: slot ids -> compact list of owned valid ids
+    int cnt = 0, ti = 0;
+    for (u32 base = c0; base < c1; base += ANN_WAVE) {
+      const u32 j = base + lane;
+      u32 id = ANN_ID_NONE;
+      if (j < c1) id = slot_id(tries, qcode, j, ti);
+      const bool ok = id < P.n && !(alias && id == x);
+      const bool own = ok && id >= P.lo && id < P.hi;
+      vtot += __popcll(__ballot(ok));
+      const u64 mm = __ballot(own);
+      if (own) list[cnt + mask_rank(mm)] = id;
+      cnt += __popcll(mm);
+    }
+    vown += cnt;
+    wave_lds_sync();
+    // ---- B: gather + distance + running selection
+    if constexpr (D > 0) {
+      typedef RowLay<D> L;
+      const int p = lane % L::LPR, g = lane / L::LPR;
+      VT bn[L::C];
+      u32 idn = 0;
+      if (cnt > 0) {
+        idn = list[g < cnt ? g : 0];
+        const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(idn - P.lo) * D) + p;
+#pragma unroll
+        for (int c = 0; c < L::C; c++) bn[c] = rp[c * L::LPR];
+      }
+      for (int base = 0; base < cnt; base += L::RPW) {
+        VT b[L::C];
+#pragma unroll
+        for (int c = 0; c < L::C; c++) b[c] = bn[c];
+        const u32 id = idn;
+        const bool act = base + g < cnt;
+        const int nb = base + L::RPW;
+        if (nb < cnt) {  // prefetch the next pass while this one is reduced
+          idn = list[nb + g < cnt ? nb + g : nb];
+          const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(idn - P.lo) * D) + p;
+#pragma unroll
+          for (int c = 0; c < L::C; c++) bn[c] = rp[c * L::LPR];
+        }
+        const FT dist = row_reduce<D, ROW_SQDIFF>(a, b);
+        const Key key = key_make(dist, id);
+        const bool pass = act && p == 0 && key_less(key, tau);
+        const u64 mm = __ballot(pass);
+        if (mm) {
+          if (pass) kbuf[kcnt + mask_rank(mm)] = key;
+          kcnt += __popcll(mm);
+          if (kcnt + L::RPW > cap) {
+            wave_lds_sync();
+            const int m = wave_select_smallest(kbuf, kcnt, K1, kout);
+            for (int i = lane; i < m; i += ANN_WAVE) kbuf[i] = kout[i];
+            if (m == K1) tau = kout[K1 - 1];
+            kcnt = m;
+            wave_lds_sync();
+          }
+        }
+      }
+    } else {
+      FT *m = yq + (size_t)(1 + w) * P.d;
+      for (int r = 0; r < cnt; r++) {
+        const u32 id = list[r];
+        const FT dist = row_reduce_generic<ROW_SQDIFF>(P.d, yq, P.points + (size_t)(id - P.lo) * P.d, m);
+        const Key key = key_make(dist, id);
+        if (key_less(key, tau)) {  // wave-uniform
+          if (lane == 0) kbuf[kcnt] = key;
+          kcnt++;
+          if (kcnt + 1 > cap) {
+            wave_lds_sync();
+            const int mk = wave_select_smallest(kbuf, kcnt, K1, kout);
+            for (int i = lane; i < mk; i += ANN_WAVE) kbuf[i] = kout[i];
+            if (mk == K1) tau = kout[K1 - 1];
+            kcnt = mk;
+            wave_lds_sync();
+          }
+        }
+      }
+    }
+    wave_lds_sync();
+  }
+
+  // ---- this wave's survivors -> merge buffer
+  wave_lds_sync();
+  {
+    const int m = wave_select_smallest(kbuf, kcnt, K1, kout);
+    for (int i = lane; i < m; i += ANN_WAVE) mbuf[(size_t)w * K1 + i] = kout[i];
+    if (lane == 0) {
+      mcnt[w] = m;
+      atomicAdd(&cnts[0], vtot);
+      atomicAdd(&cnts[1], vown);
+    }
+  }
+  __syncthreads();
+  if (w == 0) {
+    int total = 0;
+    for (int ww = 0; ww < W; ww++) {  // cap >= W*K1 (host guarantees)
+      const int m = mcnt[ww];
+      for (int i = lane; i < m; i += ANN_WAVE) kbuf[total + i] = mbuf[(size_t)ww * K1 + i];
+      total += m;
+    }
+    wave_lds_sync();
+    const int m = wave_select_smallest(kbuf, total, K1, kout);
+    for (int i = lane; i < K1; i += ANN_WAVE) {
+      cand_dist[(size_t)x * K1 + i] = i < m ? key_dist(kout[i]) : ft_inf();
+      cand_id[(size_t)x * K1 + i] = i < m ? key_id(kout[i]) : ANN_ID_NONE;
+    }
+    if (lane == 0) {
+      nv_tot[x] = cnts[0];
+      nv_own[x] = cnts[1];
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------- finalize1
+// Decide, per query, whether the K1 = k+1 smallest distinct keys determine the reference's stage-1
+// output.  They do when (a) at least k of them exist and are finite, (b) no two of them share a distance
+// (a tie between different ids is ordered by the network), and (c) the sorted prefix holds at
+// least one +inf entry or the row ends at P1 (otherwise the duplicate test at P1-1 reads slot P1's id).
+// Then the output is simply the first k keys.  Otherwise the query is appended to `flist`.
+__global__ void finalize1_kernel(int Q, int k, int K1, u32 L1, u32 P1, const FT *__restrict__ cand_dist,
+                                 const u32 *__restrict__ cand_id, const u32 *__restrict__ nv_tot,
+                                 u32 *__restrict__ top_id, FT *__restrict__ top_dist, int ostride,
+                                 int ooff, u32 *__restrict__ flist, u32 *__restrict__ fcount) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= Q) return;
+  const FT *cd = cand_dist + (size_t)x * K1;
+  const u32 *ci = cand_id + (size_t)x * K1;
+  bool flag = (u32)k > P1 || K1 != k + 1;
+  int m = 0;
+  while (m < K1 && ci[m] != ANN_ID_NONE) m++;
+  if (m < k) flag = true;
+  if (!flag) {
+    if (!(cd[k - 1] < ft_inf())) flag = true;
+    for (int t = 0; t + 1 < m; t++)
+      if (ft_bits(cd[t]) == ft_bits(cd[t + 1])) flag = true;
+    if (L1 > P1 && nv_tot[x] >= P1) flag = true;
+  }
+  if (flag) {
+    flist[atomicAdd(fcount, 1u)] = (u32)x;
+  } else {
+    for (int t = 0; t < k; t++) {
+      top_id[(size_t)x * ostride + ooff + t] = ci[t];
+      top_dist[(size_t)x * ostride + ooff + t] = cd[t];
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------- row_dists
+// Ids and distances of the first `len` slots of a row, in slot order; one workgroup per row.
+//   MODE_TABLE: stage-1 row of query x = qidx[blockIdx.x]            (len = Lc1)
+//   MODE_GRAPH: stage-2 row: slots [0,k) = current top-k with their distances, slot (y+1)k+z = z-th
+//               graph neighbour of top[y] (sentinel parents give graph[0][z] | n, Q7)   (len = Lc2)
+// Slots this device does not own, sentinels and the excluded self row get +inf; a multi-GPU caller
+// min-reduces the distance rows across devices before exact_select.
+enum { MODE_TABLE = 0, MODE_GRAPH = 1 };
+#define ANN_RD_CHUNK 2048
+
+template <int D, int MODE>
+__global__ __launch_bounds__(256) void row_dists_kernel(QParams P, int Q, const FT *__restrict__ y,
+                                                        int alias, const u32 *__restrict__ codes,
+                                                        const u32 *__restrict__ qidx, u32 xbase,
+                                                        u32 len, const u32 *__restrict__ top_id,
+                                                        const FT *__restrict__ top_dist,
+                                                        u32 *__restrict__ ids_out,
+                                                        FT *__restrict__ dist_out,
+                                                        unsigned long long *__restrict__ rows_done) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = lane_id(), w = threadIdx.x >> 6, W = blockDim.x >> 6;
+  const u32 x = qidx ? qidx[blockIdx.x] : xbase + blockIdx.x;
+  u32 *ids_row = ids_out + (size_t)blockIdx.x * len;
+  FT *dist_row = dist_out + (size_t)blockIdx.x * len;
+  unsigned char *sp = smem;
+  u32 *lslot = reinterpret_cast<u32 *>(sp);           sp += sizeof(u32) * ANN_RD_CHUNK;
+  u32 *lid = reinterpret_cast<u32 *>(sp);             sp += sizeof(u32) * ANN_RD_CHUNK;
+  TryInfo *tries = reinterpret_cast<TryInfo *>(sp);   sp += sizeof(TryInfo) * (size_t)P.T;
+  u32 *qcode = reinterpret_cast<u32 *>(sp);           sp += sizeof(u32) * (size_t)P.T;
+  u32 *lcount = reinterpret_cast<u32 *>(sp);          sp += sizeof(u32) * 4;
+  sp = smem + (((sp - smem) + 15) & ~(size_t)15);
+  FT *yq = reinterpret_cast<FT *>(sp);
+
+  if (MODE == MODE_TABLE)
+    for (int i = threadIdx.x; i < P.T; i += blockDim.x) {
+      tries[i] = P.tries[i];
+      qcode[i] = codes[(size_t)i * Q + x];
+    }
+  if constexpr (D == 0)
+    for (int z = threadIdx.x; z < P.d; z += blockDim.x) yq[z] = y[(size_t)x * P.d + z];
+  VT a[D > 0 ? RowLay<(D > 0 ? D : 16)>::C : 1];
+  if constexpr (D > 0) {
+    typedef RowLay<D> L;
+    const VT *yp = reinterpret_cast<const VT *>(y + (size_t)x * D) + (lane % L::LPR);
+#pragma unroll
+    for (int c = 0; c < L::C; c++) a[c] = yp[c * L::LPR];
+  }
+  u32 gathered = 0;
+  for (u32 c0 = 0; c0 < len; c0 += ANN_RD_CHUNK) {
+    const u32 c1 = min(len, c0 + ANN_RD_CHUNK);
+    if (threadIdx.x == 0) lcount[0] = 0;
+    __syncthreads();
+    for (u32 j = c0 + threadIdx.x; j < c1; j += blockDim.x) {
+      u32 id;
+      bool given = false;
+      if (MODE == MODE_TABLE) {
+        int ti = 0;
+        id = slot_id(tries, qcode, j, ti);
+      } else {
+        const u32 k = P.k;
+        if (j < k) {
+          id = top_id[(size_t)x * k + j];
+          given = true;
+        } else {
+          const u32 parent = top_id[(size_t)x * k + (j / k - 1)];
+          const u32 z = j % k;
+          id = parent < P.n ? P.graph[(size_t)parent * k + z] : (P.graph[z] | P.n);
+        }
+      }
+      ids_row[j] = id;
+      if (given) {
+        dist_row[j] = top_dist[(size_t)x * P.k + j];
+      } else {
+        const bool own = id < P.n && !(alias && id == x) && id >= P.lo && id < P.hi;
+        if (own) {
+          const u32 pos = atomicAdd(&lcount[0], 1u);
+          lslot[pos] = j;
+          lid[pos] = id;
+        } else {
+          dist_row[j] = ft_inf();
+        }
+      }
+    }
+    __syncthreads();
+    const int cnt = (int)lcount[0];
+    gathered += cnt;
+    if constexpr (D > 0) {
+      typedef RowLay<D> L;
+      const int p = lane % L::LPR, g = lane / L::LPR;
+      for (int base = w * L::RPW; base < cnt; base += W * L::RPW) {
+        const int r = base + g;
+        const bool act = r < cnt;
+        const u32 id = lid[act ? r : base];
+        const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(id - P.lo) * D) + p;
+        VT b[L::C];
+#pragma unroll
+        for (int c = 0; c < L::C; c++) b[c] = rp[c * L::LPR];
+        const FT dist = row_reduce<D, ROW_SQDIFF>(a, b);
+        if (act && p == 0) dist_row[lslot[r]] = dist;
+      }
+    } else {
+      FT *m = yq + (size_t)(1 + w) * P.d;
+      for (int r = w; r < cnt; r += W) {
+        const u32 id = lid[r];
+        const FT dist = row_reduce_generic<ROW_SQDIFF>(P.d, yq, P.points + (size_t)(id - P.lo) * P.d, m);
+        if (lane == 0) dist_row[lslot[r]] = dist;
+      }
+    }
+    __syncthreads();
+  }
+  if (rows_done && threadIdx.x == 0) atomicAdd(rows_done, (unsigned long long)gathered);
+}
+
+// ----------------------------------------------------------------------------------- exact_select
+// sort_and_uniq (alg.c:224-230) on `len` stored entries of a row of reference length L, then the first k
+// entries out.  One workgroup per row.  USE_LDS: the row is staged in LDS, otherwise the network runs in
+// place in global memory (rows too long for LDS; the workgroup owns the row).
+template <bool USE_LDS>
+__global__ __launch_bounds__(256) void exact_select_kernel(u32 L, u32 len, u32 in_stride, int k,
+                                                           u32 *__restrict__ ids_in,
+                                                           FT *__restrict__ dist_in,
+                                                           const u32 *__restrict__ qidx, u32 xbase,
+                                                           u32 *__restrict__ out_id,
+                                                           FT *__restrict__ out_dist, int ostride,
+                                                           int ooff) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const u32 x = qidx ? qidx[blockIdx.x] : xbase + blockIdx.x;
+  u32 *gi = ids_in + (size_t)blockIdx.x * in_stride;
+  FT *gd = dist_in + (size_t)blockIdx.x * in_stride;
+  if (USE_LDS) {
+    FT *sd = reinterpret_cast<FT *>(smem);
+    u32 *si = reinterpret_cast<u32 *>(sd + len);
+    for (u32 j = threadIdx.x; j < len; j += blockDim.x) sd[j] = gd[j], si[j] = gi[j];
+    __syncthreads();
+    block_topk_stage(L, len, sd, si);
+    for (int t = threadIdx.x; t < k; t += blockDim.x) {
+      out_id[(size_t)x * ostride + ooff + t] = si[t];
+      out_dist[(size_t)x * ostride + ooff + t] = sd[t];
+    }
+  } else {
+    block_topk_stage(L, len, gd, gi);
+    for (int t = threadIdx.x; t < k; t += blockDim.x) {
+      out_id[(size_t)x * ostride + ooff + t] = gi[t];
+      out_dist[(size_t)x * ostride + ooff + t] = gd[t];
+    }
+  }
+}
+
+// u32 ids -> the ABI's size_t ids
+__global__ void widen_ids_kernel(size_t count, const u32 *__restrict__ in, size_t *__restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) out[i] = in[i];
+}
+__global__ void narrow_ids_kernel(size_t count, const size_t *__restrict__ in, u32 *__restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) out[i] = (u32)in[i];
+}

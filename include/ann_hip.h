@@ -1,0 +1,98 @@
+/* ann_hip.h -- the resident / staged C-ABI of the HIP backend.
+ *
+ * query_gpu()/precomp_gpu() (algg.h) are the drop-in symbols; they are thin wrappers over the calls
+ * below, which keep the index resident in HBM between calls and expose the stages of the query path
+ * so that a multi-GPU host (one process per GPU, point rows sharded) can put its RCCL exchanges between
+ * them.  Plain pointers and sizes only; "dev" pointers are HIP device pointers of the current device.
+ *
+ * The reference has no counterpart for residency: its GPU path re-wraps points, graph and every bucket
+ * table as CL_MEM_USE_HOST_PTR buffers on every call (/root/reference/alg.c:444-445,503-508).
+ */
+#ifndef APPROXNN_HIP_ANN_HIP_H
+#define APPROXNN_HIP_ANN_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#include "ann.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct annhip_index annhip_index;
+
+/* "f32" or "f64": the precision this library was built for (ftype.h). */
+const char *annhip_precision(void);
+
+/* ---- index lifecycle ------------------------------------------------------------------------- */
+/* Upload an index.  `points` holds rows [row_lo,row_hi) only (row-major, save->d_long each): the rows
+ * this device owns.  points_on_device != 0: `points` is a device pointer that the index borrows (the
+ * caller keeps it alive); otherwise it is host memory and is copied.  Single GPU: row_lo=0,row_hi=n. */
+annhip_index *annhip_index_create(const save_t *save, const ftype *points, int points_on_device,
+                                  size_t row_lo, size_t row_hi);
+void annhip_index_destroy(annhip_index *ix);
+/* out[0..11] = n, k, d, d_short, tries, L1, P1, Lc1, L2, P2, Lc2, sum(par_maxes)  (SURVEY 8 notation) */
+void annhip_index_info(const annhip_index *ix, size_t out[12]);
+/* All launches of this index go to `hip_stream` (a hipStream_t; NULL = the default stream). */
+void annhip_index_set_stream(annhip_index *ix, void *hip_stream);
+/* Download the index into a save_t whose fields are malloc'd (free_save() releases it). */
+void annhip_index_export(const annhip_index *ix, save_t *save);
+
+/* ---- precomp on the device (alg.c:342-434) ----------------------------------------------------- */
+/* Builds the index from ALL n rows on this device and keeps it resident.  Consumes libc random() in the
+ * reference's order.  graph_dists_dev (device, ftype[n*k]) may be NULL. */
+annhip_index *annhip_precomp_index(size_t n, size_t k, size_t d, const ftype *points,
+                                   int points_on_device, int tries, size_t rots_before,
+                                   size_t rot_len_before, size_t rots_after, size_t rot_len_after,
+                                   ftype *graph_dists_dev);
+
+/* ---- whole query on one device (alg.c:458-519) ------------------------------------------------- */
+/* y_dev: ftype[ycnt][d]; alias != 0: query x excludes point x (the y == points case, compute.cl:144-146).
+ * mode 0: selection path with exact fallback; mode 1: exact path for every query.
+ * ids_dev: size_t[ycnt][k], dists_dev: ftype[ycnt][k] (may be NULL).  Returns the number of queries that
+ * took the exact path.  Asynchronous on the index's stream except for one 4-byte read-back. */
+long annhip_query(annhip_index *ix, size_t ycnt, const ftype *y_dev, int alias, int mode,
+                  size_t *ids_dev, ftype *dists_dev);
+
+/* ---- staged query, for point-sharded multi-GPU hosts -------------------------------------------- */
+/* 1. hash codes of the whole batch: codes_dev u32[ycnt*tries], layout [q*tries+t] (alg.c:462-492).     */
+void annhip_codes(annhip_index *ix, size_t ycnt, const ftype *y_dev, uint32_t *codes_dev);
+/* 2. this device's k+1 best distinct candidates per query among the rows it owns:
+ *    cand_dist ftype[ycnt][k+1], cand_id u32[ycnt][k+1] (ascending, padded (+inf,0xFFFFFFFF));
+ *    nvalid u32[ycnt] = valid slots in the sorted prefix on ANY device (identical on every device).       */
+void annhip_stage1_local(annhip_index *ix, size_t ycnt, const ftype *y_dev, int alias,
+                         const uint32_t *codes_dev, ftype *cand_dist_dev, uint32_t *cand_id_dev,
+                         uint32_t *nvalid_dev);
+/* 3. after the caller merged all devices' candidates into the k+1 globally best (same format):
+ *    writes top_id u32[ycnt][k]/top_dist and the list of queries that need the exact path.
+ *    Returns their count (synchronises). flagged_dev must hold ycnt entries.                             */
+long annhip_stage1_finalize(annhip_index *ix, size_t ycnt, const ftype *cand_dist_dev,
+                            const uint32_t *cand_id_dev, const uint32_t *nvalid_dev,
+                            uint32_t *top_id_dev, ftype *top_dist_dev, uint32_t *flagged_dev);
+/* 4. exact path, part 1: ids u32[nq][Lc1] and distances ftype[nq][Lc1] of the first Lc1 slots of the
+ *    queries listed in qidx_dev (NULL = queries 0..nq-1); slots not owned here get +inf (min-reduce the
+ *    distance rows across devices).                                                                       */
+void annhip_stage1_rows(annhip_index *ix, size_t ycnt, const ftype *y_dev, int alias,
+                        const uint32_t *codes_dev, const uint32_t *qidx_dev, size_t nq,
+                        uint32_t *ids_dev, ftype *dist_dev);
+/* 5. stage-2 rows: ids u32[ycnt][Lc2], distances ftype[ycnt][Lc2] from the current top-k.                */
+void annhip_stage2_rows(annhip_index *ix, size_t ycnt, const ftype *y_dev, int alias,
+                        const uint32_t *top_id_dev, const ftype *top_dist_dev, uint32_t *ids_dev,
+                        ftype *dist_dev);
+/* 6. the reference's network+rdups+network on rows of reference length L (stage: 1 -> L1, 2 -> L2),
+ *    first k entries to out_id u32[.][k] / out_dist at row qidx_dev[i] (NULL = i).                        */
+void annhip_exact_select(annhip_index *ix, int stage, size_t nq, uint32_t *ids_dev, ftype *dist_dev,
+                         const uint32_t *qidx_dev, uint32_t *out_id_dev, ftype *out_dist_dev);
+/* u32 -> size_t on the device */
+void annhip_widen_ids(annhip_index *ix, size_t count, const uint32_t *in_dev, size_t *out_dev);
+
+/* ---- measurement ---------------------------------------------------------------------------------- */
+/* profile != 0: bracket every stage1 launch with HIP events on the index's stream. */
+void annhip_profile(annhip_index *ix, int profile);
+/* out[0]=stage-1 launches, out[1]=their total ms (events), out[2]=rows gathered in stage 1 (owned valid
+ * slots), out[3]=rows gathered in stage-2/exact rows kernels, out[4]=queries through the exact path,
+ * out[5]=queries seen; counters accumulate since the last reset (reset != 0 clears them after reading). */
+void annhip_stats(annhip_index *ix, double out[8], int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,114 @@
+"""GPU parity: the HIP path (through the C-ABI) against the golden vectors recorded from the compiled
+reference and against the oracle on fresh seeded inputs.  Bit-exact ids AND bit-exact distances: the
+kernels use the reference's operation order, so the 1e-5 relative tolerance north_star allows for float
+distances is never needed (it is asserted as the outer bound anyway)."""
+import os
+
+import numpy as np
+import pytest
+
+import approximatenn_amd as A
+from oracle import oracle_py as O
+from tests.util import assert_save_equal, bits_equal, golden_cases, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(ids, dists, g_ids, g_dists, what):
+    assert np.array_equal(ids, g_ids), "%s: ids differ in %d places" % (what, int(np.sum(ids != g_ids)))
+    fin = np.isfinite(g_dists)
+    np.testing.assert_allclose(dists[fin], g_dists[fin], rtol=1e-5, err_msg=what)
+    assert bits_equal(dists, g_dists), "%s: distances not bit-identical" % what
+
+
+@pytest.fixture(params=["select", "exact"])
+def path_mode(request):
+    """'select' = production path (selection + exact fallback); 'exact' = the reference network for every row."""
+    if request.param == "exact":
+        os.environ["ANN_HIP_EXACT"] = "1"
+    else:
+        os.environ.pop("ANN_HIP_EXACT", None)
+    yield request.param
+    os.environ.pop("ANN_HIP_EXACT", None)
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_query_matches_golden(name, path_mode):
+    g = load_golden(name)
+    save = A.Save.from_dict(g["prec"], g["save"])
+    pts = np.ascontiguousarray(g["points"])
+    ids, dists = A.query(save, pts, g["y"])
+    _check(ids, dists, g["query_ids"], g["query_dists"], name + " query")
+    qa = len(g["alias_ids"])
+    ids, dists = A.query(save, pts, pts[:qa])  # same buffer => self excluded (Q3)
+    _check(ids, dists, g["alias_ids"], g["alias_dists"], name + " alias")
+    ids, dists = A.query(save, pts, pts[:qa].copy())
+    _check(ids, dists, g["copy_ids"], g["copy_dists"], name + " copy")
+    A._lib.load(g["prec"]).annhip_cache_clear()
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_precomp_matches_golden(name, path_mode):
+    g = load_golden(name)
+    c = g["cfg"]
+    pts = np.ascontiguousarray(g["points"])
+    # same libc stream position as the generator had after drawing the points
+    O.srandom(c["seed"])
+    orc = O.CpuBackend(g["prec"], "oracle")
+    orc.rand_norm_reset()
+    orc.gen_rand(c["n"] * c["d"] + (c["n"] * c["d"]) % 2)
+    ids, dists, save = A.precomp(pts, c["k"], c["tries"], c["rb"], c["rlb"], c["ra"], c["rla"])
+    try:
+        _check(ids, dists, g["precomp_ids"], g["precomp_dists"], name + " precomp")
+        assert_save_equal(save.to_dict(), g["save"])
+        # the freshly built (resident) index answers queries like the reference's
+        q_ids, q_d = A.query(save, pts, g["y"])
+        _check(q_ids, q_d, g["query_ids"], g["query_dists"], name + " query after precomp")
+    finally:
+        A._lib.load(g["prec"]).annhip_cache_clear()
+        save.free()
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("case", [(3000, 64, 10, 10, 500), (2500, 128, 8, 6, 300), (1800, 80, 10, 10, 120),
+                                  (4000, 16, 5, 8, 700), (1200, 256, 10, 4, 64), (900, 40, 20, 3, 50)])
+def test_against_oracle_fresh_inputs(prec, case):
+    """Seeded inputs never seen by the fixtures: GPU precomp+query vs the oracle, all fields bit-exact."""
+    n, d, k, T, Q = case
+    orc = O.CpuBackend(prec, "oracle")
+    O.srandom(1000 + n + d)
+    orc.rand_norm_reset()
+    pts = orc.gen_rand(n * d).reshape(n, d)
+    y = orc.gen_rand(Q * d).reshape(Q, d)
+    O.srandom(31)
+    o_ids, o_d, o_save = orc.precomp(pts, k, T)
+    O.srandom(31)
+    ids, dists, save = A.precomp(pts, k, T)
+    try:
+        _check(ids, dists, o_ids, o_d, "precomp")
+        assert_save_equal(save.to_dict(), o_save)
+        oq = orc.query(o_save, pts, y)
+        gq = A.query(save, pts, y)
+        _check(gq[0], gq[1], oq[0], oq[1], "query")
+        oa = orc.query(o_save, pts, min(Q, n), alias=True)
+        ga = A.query(save, pts, pts[: min(Q, n)])
+        _check(ga[0], ga[1], oa[0], oa[1], "alias query")
+    finally:
+        A._lib.load(prec).annhip_cache_clear()
+        save.free()
+
+
+def test_resident_index_device_tensors():
+    import torch
+    g = load_golden("pow2_d128_f32")
+    save = A.Save.from_dict("f32", g["save"])
+    pts = torch.from_numpy(g["points"]).cuda()
+    ix = A.Index.from_save(save, pts)
+    y = torch.from_numpy(g["y"]).cuda()
+    for mode in (0, 1):
+        ids, dists, nex = ix.query(y, mode=mode)
+        torch.cuda.synchronize()
+        _check(ids.cpu().numpy().astype(np.uint64), dists.cpu().numpy(), g["query_ids"], g["query_dists"], "resident")
+    st = ix.stats()
+    assert st["queries"] == 2 * len(g["y"]) and st["s1_rows"] > 0
+    ix.close()
