@@ -36,6 +36,13 @@ def load(prec="f32"):
     assert prec in ("f32", "f64")
     if prec in _libs:
         return _libs[prec]
+    # One HIP runtime per process: torch preloads its bundled libamdhip64.so.7 by path, so it has to be in the
+    # process BEFORE this library's NEEDED libamdhip64.so.7 is resolved (same SONAME => the loaded one is reused).
+    # Loading in the other order leaves two runtimes and the second one finds no device.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = lib_path(prec)
     if not os.path.exists(path):
         raise ImportError("HIP backend %s is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -49,6 +56,7 @@ def load(prec="f32"):
     lib.annhip_index_info.argtypes = [vp, C.POINTER(sz * 12)]
     lib.annhip_index_set_stream.argtypes = [vp, vp]
     lib.annhip_index_export.argtypes = [vp, C.POINTER(SaveT)]
+    lib.annhip_index_reshard.argtypes = [vp, vp, sz, sz]
     lib.annhip_precomp_index.restype = vp
     lib.annhip_precomp_index.argtypes = [sz, sz, sz, vp, C.c_int, C.c_int, sz, sz, sz, sz, vp]
     lib.annhip_query.restype = C.c_long
@@ -78,7 +86,7 @@ def load(prec="f32"):
 # every symbol include/*.h declares for the backend library (checked by tests/test_abi.py)
 EXPORTED = ["gpu_init", "gpu_cleanup", "register_cleanup", "query_gpu", "precomp_gpu", "annhip_precision",
             "annhip_index_create", "annhip_index_destroy", "annhip_index_info", "annhip_index_set_stream",
-            "annhip_index_export", "annhip_precomp_index", "annhip_query", "annhip_codes", "annhip_stage1_local",
+            "annhip_index_export", "annhip_index_reshard", "annhip_precomp_index", "annhip_query", "annhip_codes", "annhip_stage1_local",
             "annhip_stage1_finalize", "annhip_stage1_rows", "annhip_stage2_rows", "annhip_exact_select",
             "annhip_widen_ids", "annhip_profile", "annhip_stats"]
 DISPATCH_EXPORTED = ["precomp", "query", "free_save"]

@@ -197,6 +197,13 @@ class Index:
         s._malloced = True
         return s
 
+    def reshard(self, shard_points, row_lo, row_hi):
+        """annhip_index_reshard: own rows [row_lo,row_hi) only, read from the torch device tensor shard_points."""
+        assert shard_points.is_cuda and shard_points.is_contiguous() and tuple(shard_points.shape) == (row_hi - row_lo, self.d)
+        self.lib.annhip_index_reshard(self.h, shard_points.data_ptr(), row_lo, row_hi)
+        self._keep = (shard_points,)
+        self.row_lo, self.row_hi = row_lo, row_hi
+
     def set_stream(self, stream_ptr):
         self.lib.annhip_index_set_stream(self.h, stream_ptr)
 

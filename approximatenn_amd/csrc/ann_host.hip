@@ -35,6 +35,16 @@ static void die(const char *msg) {
   exit(1);
 }
 
+// The HIP runtime consumes libc random() while it initialises (observed on ROCm 7.2: the first precomp after
+// srandom(s) drew different rotations than the second).  The reference's callers own that stream (seeded
+// drivers, compare_results.c:124-130), so every entry point parks it while HIP code runs.
+struct RandGuard {
+  char scratch[256];
+  char *saved;
+  RandGuard() { saved = initstate(1u, scratch, sizeof scratch); }
+  ~RandGuard() { setstate(saved); }
+};
+
 // ----------------------------------------------------------------------------- device lifecycle
 static bool g_init = false;
 struct CleanupNode {
@@ -46,6 +56,7 @@ static void cache_clear();
 
 extern "C" void gpu_init(void) {
   if (g_init) return;
+  RandGuard keep_callers_stream;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
     fprintf(stderr, "No GPU found.\n");  // same message as gpu_comp.c:85-90
@@ -138,6 +149,7 @@ struct annhip_index {
   TryInfo *d_tries = NULL;
   u32 *d_graph = NULL;
   FT *d_means = NULL, *d_bases = NULL;
+  FT *d_graph_dists = NULL;  // precomp only: squared distances of the graph edges until the caller takes them
   u32 L1 = 0, P1 = 0, Lc1 = 0, L2 = 0, P2 = 0, Lc2 = 0;
   size_t sum_pm = 0;
   hipStream_t stream = 0;
@@ -253,6 +265,15 @@ extern "C" annhip_index *annhip_index_create(const save_t *save, const ftype *po
   return ix;
 }
 
+extern "C" void annhip_index_reshard(annhip_index *ix, const ftype *shard_points_dev, size_t row_lo, size_t row_hi) {
+  if (row_lo > row_hi || row_hi > ix->n) die("bad row range");
+  HIPCHECK(hipDeviceSynchronize());
+  if (ix->own_points && ix->d_points) HIPCHECK(hipFree(ix->d_points));
+  ix->own_points = false;
+  ix->d_points = const_cast<FT *>(reinterpret_cast<const FT *>(shard_points_dev));
+  ix->lo = row_lo, ix->hi = row_hi;
+}
+
 extern "C" void annhip_index_destroy(annhip_index *ix) {
   if (!ix) return;
   HIPCHECK(hipDeviceSynchronize());
@@ -263,6 +284,7 @@ extern "C" void annhip_index_destroy(annhip_index *ix) {
   if (ix->d_graph) HIPCHECK(hipFree(ix->d_graph));
   if (ix->d_means) HIPCHECK(hipFree(ix->d_means));
   if (ix->d_bases) HIPCHECK(hipFree(ix->d_bases));
+  if (ix->d_graph_dists) HIPCHECK(hipFree(ix->d_graph_dists));
   if (ix->d_fcount) HIPCHECK(hipFree(ix->d_fcount));
   if (ix->d_rows) HIPCHECK(hipFree(ix->d_rows));
   DevBuf *bufs[] = {&ix->codes, &ix->cand_d, &ix->cand_i, &ix->nvt, &ix->nvo, &ix->top_i, &ix->top_d,
@@ -690,7 +712,6 @@ static T *upload_vec(const std::vector<T> &v, std::vector<void *> &owned) {
 extern "C" annhip_index *annhip_precomp_index(size_t n, size_t k, size_t d, const ftype *points, int on_device,
                                               int tries, size_t rots_before, size_t rot_len_before,
                                               size_t rots_after, size_t rot_len_after, ftype *graph_dists_dev) {
-  gpu_init();
   if (n <= k || k < 1) die("need n > k >= 1");
   // alg.c:347-357 (Q13: evaluated in ftype)
   size_t ds = (size_t)ceil(log2((FT)n / k));
@@ -700,6 +721,17 @@ extern "C" annhip_index *annhip_precomp_index(size_t n, size_t k, size_t d, cons
   check_limits(n, k, d, ds, tries);
   if (2 * rot_len_before > d || 2 * rot_len_after > ds) die("rotation length exceeds dimension (rand_rot needs 2*len <= dim)");
   const int T = tries;
+  // Every transform is drawn up front, in the reference's order (alg.c:387-392, Q12), and BEFORE any HIP call:
+  // these draws are the only use this path makes of the caller's random() stream.
+  std::vector<HostXform> hx(T);
+  for (int t = 0; t < T; t++) {
+    hx[t].before = draw_givens(rots_before, rot_len_before, d);
+    hx[t].after = draw_givens(rots_after, rot_len_after, ds);
+    hx[t].perm_b = draw_perm(d, d_max);
+    hx[t].perm_ai = draw_perm(ds, d_max);
+  }
+  RandGuard keep_callers_stream;
+  gpu_init();
   const bool exact_all = getenv("ANN_HIP_EXACT") != NULL;
   hipStream_t s = 0;
 
@@ -726,15 +758,6 @@ extern "C" annhip_index *annhip_precomp_index(size_t n, size_t k, size_t d, cons
     centre_kernel<<<grid_for(n * d, 256, 16384), 256, 0, s>>>(n, d, pts, ix->d_means, centred);
     HIPCHECK(hipStreamSynchronize(s));
     HIPCHECK(hipFree(acc));
-  }
-
-  // every transform is drawn before any other use of the stream (alg.c:387-392, Q12)
-  std::vector<HostXform> hx(T);
-  for (int t = 0; t < T; t++) {
-    hx[t].before = draw_givens(rots_before, rot_len_before, d);
-    hx[t].after = draw_givens(rots_after, rot_len_after, ds);
-    hx[t].perm_b = draw_perm(d, d_max);
-    hx[t].perm_ai = draw_perm(ds, d_max);
   }
 
   // hash codes per try (run_initial) and the projection rows (save_vecs)
@@ -861,7 +884,7 @@ extern "C" annhip_index *annhip_precomp_index(size_t n, size_t k, size_t d, cons
   }
   HIPCHECK(hipFree(top_i));
   HIPCHECK(hipFree(top_d));
-  if (!graph_dists_dev) HIPCHECK(hipFree(gd));
+  if (!graph_dists_dev) ix->d_graph_dists = gd;
   return ix;
 }
 
@@ -932,6 +955,7 @@ static annhip_index *cache_get(const save_t *sv, const ftype *points) {
 // ----------------------------------------------------------------------------- drop-in symbols
 extern "C" size_t *query_gpu(const save_t *save, const ftype *points, size_t ycnt, const ftype *y,
                              ftype **dists_o) {
+  RandGuard keep_callers_stream;
   gpu_init();
   annhip_index *ix = cache_get(save, points);
   const size_t k = save->k, d = save->d_long;
@@ -955,10 +979,11 @@ extern "C" size_t *query_gpu(const save_t *save, const ftype *points, size_t ycn
 extern "C" size_t *precomp_gpu(size_t n, size_t k, size_t d, const ftype *points, int tries,
                                size_t rots_before, size_t rot_len_before, size_t rots_after,
                                size_t rot_len_after, save_t *save, ftype **dists_o) {
-  gpu_init();
-  FT *gd = dev_alloc<FT>(n * k);
+  // (annhip_precomp_index draws from the caller's random() stream first, then parks it)
   annhip_index *ix = annhip_precomp_index(n, k, d, points, 0, tries, rots_before, rot_len_before, rots_after,
-                                          rot_len_after, gd);
+                                          rot_len_after, NULL);
+  RandGuard keep_callers_stream;
+  FT *gd = ix->d_graph_dists;
   size_t *result = (size_t *)malloc(sizeof(size_t) * n * k);
   size_t *wide = dev_alloc<size_t>(n * k);
   widen_ids_kernel<<<grid_for(n * k, 256, 1u << 30), 256>>>(n * k, ix->d_graph, wide);
@@ -969,6 +994,7 @@ extern "C" size_t *precomp_gpu(size_t n, size_t k, size_t d, const ftype *points
     HIPCHECK(hipMemcpy(*dists_o, gd, sizeof(FT) * n * k, hipMemcpyDeviceToHost));
   }
   HIPCHECK(hipFree(gd));
+  ix->d_graph_dists = NULL;
   if (save) {
     annhip_index_export(ix, save);
     // keep the freshly built index resident for the queries that normally follow (time_results.c:95-105)

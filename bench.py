@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- queries/s of the query() hot path on MI355X, BASELINE.json's metric.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[2], "cfg3"): N=10M points, d=128, k=10, tries=10, float, Q=10k queries per
+GPU per step, synthetic N(0,1) data generated on the device (no dataset exists for this path).  One step =
+one query() batch: hash codes -> candidate gather + squared L2 + top-k selection (+ exact fallback) ->
+neighbour-of-neighbour refinement -> ids/distances, inputs and index resident in HBM.
+
+N > 1: the point rows are sharded across the ranks (each GPU gathers only rows it owns), per-shard top-(k+1)
+candidates are all-gathered over RCCL and merged, stage-2 distance rows are min-all-reduced.  The batch grows
+with N (Q = 10k x N queries per step, every rank sees all of them), so per-GPU gather work stays fixed:
+"scaling": "weak".  value = total queries / max-over-ranks time.
+
+The JSON line also carries
+  roofline     : the dominant kernel (stage1_select) priced at its ALGORITHMIC bytes / HIP-event duration
+  cpu_baseline : the oracle (CPU restatement, 1 core) timed on a bounded sample of the same workload on the
+                 same index, on rank 0 at N=1 only -- and its results are compared with the GPU's (parity).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md; ~6.3 TB/s is the measured copy rate)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=10_000_000)
+    ap.add_argument("--d", type=int, default=128)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--tries", type=int, default=10)
+    ap.add_argument("--q", type=int, default=10_000, help="queries per GPU per step")
+    ap.add_argument("--seed", type=int, default=12345)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    import approximatenn_amd as A
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+    shared_gpu = os.environ.get("ANN_BENCH_SHARED_GPU") == "1"  # rehearsal: all ranks on GPU 0, gloo collectives
+    dev_index = 0 if shared_gpu else local_rank
+    os.environ["ANN_HIP_DEVICE"] = str(dev_index)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    if world > 1:
+        backend = "gloo" if shared_gpu else "nccl"  # "nccl" is RCCL on ROCm
+        dist.init_process_group(backend=backend)
+
+    n, d, k, T = args.n, args.d, args.k, args.tries
+    Q = args.q * world  # weak scaling: the batch grows with the number of shards
+    libc = ctypes.CDLL("libc.so.6")
+
+    # ---- synthetic data + index (identical on every rank: same seeds, deterministic build)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(args.seed)
+    points = torch.randn((n, d), device=device, dtype=torch.float32, generator=gen)
+    libc.srandom(args.seed)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    ix = A.Index.precomp(points, k, T)
+    torch.cuda.synchronize()
+    precomp_s = time.time() - t0
+    ix.set_stream(torch.cuda.current_stream().cuda_stream)
+    batches = [torch.randn((Q, d), device=device, dtype=torch.float32, generator=gen)
+               for _ in range(args.warmup + args.steps)]
+
+    if world > 1:
+        from approximatenn_amd.sharded import ShardedQuery
+        lo, hi = (n * rank) // world, (n * (rank + 1)) // world
+        shard = points[lo:hi].clone()
+        ix.reshard(shard, lo, hi)
+        del points
+        torch.cuda.empty_cache()
+        runner = ShardedQuery(ix, dist)
+        step = lambda y: runner.query(y)
+    else:
+        out_ids = torch.empty((Q, k), dtype=torch.int64, device=device)
+        out_d = torch.empty((Q, k), dtype=torch.float32, device=device)
+        step = lambda y: ix.query(y, out_ids=out_ids, out_dists=out_d)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step(batches[i])
+    torch.cuda.synchronize()
+    ix.stats(reset=True)
+    ix.profile(True)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(batches[args.warmup + i])
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device if not shared_gpu else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    st = ix.stats()
+    ix.profile(False)
+
+    # ---- roofline of the dominant kernel (stage1_select): algorithmic bytes / HIP-event time
+    launches = max(st["s1_launches"], 1.0)
+    v1 = st["s1_rows"] / max(st["queries"], 1.0)            # rows THIS device gathered per query
+    kern_ms = st["s1_ms"] / launches
+    bytes_per_query = v1 * d * 4 + ix.P1 * 4 + d * 4 + T * 4 + (k + 1) * 8
+    bytes_per_launch = bytes_per_query * Q
+    achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "stage1_select_kernel<128>", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                "rows_gathered_per_query": round(v1, 1)}
+
+    value = Q * args.steps / elapsed
+    line = {"metric": "queries/sec, N=10M d=128 k=10 Q=10k float (query(): hash + candidate gather + L2 + top-k + refine)",
+            "value": round(value, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cfg3: N=%d d=%d k=%d tries=%d Q=%d/step float, randn points+queries" % (n, d, k, T, Q),
+                       "points_sharding": "rows/%d" % world, "d_short": ix.d_short, "L1": ix.L1, "P1": ix.P1,
+                       "L2": ix.L2, "P2": ix.P2, "sum_par_maxes": ix.sum_pm, "precomp_s": round(precomp_s, 2),
+                       "exact_path_queries_per_step": round(st["exact_queries"] / args.steps, 2)},
+            "roofline": roofline}
+
+    # ---- CPU baseline + full-size parity sample (rank 0, single GPU only)
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(args, ix, points, batches[0], libc)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    ix.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, ix, points, y_dev, libc):
+    """Oracle (oracle/ann_oracle.c, single thread) on a bounded sample, on the same index, checked against the GPU."""
+    import numpy as np
+    import torch
+
+    from oracle import oracle_py as O
+    save = ix.export()
+    arrays = save.to_dict()
+    save.free()
+    host_pts = points.cpu().numpy()
+    orc = O.CpuBackend("f32", "oracle")
+    hs = O.HostSave(arrays, "f32")
+    qs = 64
+    y = y_dev[:qs].cpu().numpy()
+    t0 = time.perf_counter()
+    orc.query(hs, host_pts, y)
+    rate = qs / (time.perf_counter() - t0)
+    qs = int(max(64, min(len(y_dev), rate * args.cpu_seconds)))
+    y = np.ascontiguousarray(y_dev[:qs].cpu().numpy())
+    t0 = time.perf_counter()
+    o_ids, o_d = orc.query(hs, host_pts, y)
+    cpu_s = time.perf_counter() - t0
+    g_ids, g_d, _ = ix.query(y_dev[:qs].contiguous())
+    torch.cuda.synchronize()
+    ids_equal = bool(np.array_equal(g_ids.cpu().numpy().astype(np.uint64), o_ids))
+    d_equal = bool(np.array_equal(g_d.cpu().numpy().view(np.uint32), o_d.view(np.uint32)))
+    return {"value": round(qs / cpu_s, 2), "unit": "queries/s", "cores": 1, "kind": "port",
+            "sample": "%d-query batch of the same workload on the GPU-built index (oracle, 1 thread, %.1f s)" % (qs, cpu_s),
+            "host_cores_available": os.cpu_count(),
+            "parity_on_sample": {"ids_bit_exact": ids_equal, "dists_bit_exact": d_equal}}
+
+
+if __name__ == "__main__":
+    main()

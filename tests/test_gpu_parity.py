@@ -112,3 +112,15 @@ def test_resident_index_device_tensors():
     st = ix.stats()
     assert st["queries"] == 2 * len(g["y"]) and st["s1_rows"] > 0
     ix.close()
+
+
+def test_precomp_is_first_gpu_call_in_a_fresh_process():
+    """HIP runtime start-up consumes libc random(); the index must not depend on whether the runtime was
+    already up when precomp() drew its rotations (regression: first precomp after srandom() differed)."""
+    import subprocess
+    import sys
+    code = ("import __graft_entry__ as g; g.smoke()")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "smoke ok" in out.stdout
