@@ -10,6 +10,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "../../include/algg.h"
@@ -38,11 +40,20 @@ static void die(const char *msg) {
 // The HIP runtime consumes libc random() while it initialises (observed on ROCm 7.2: the first precomp after
 // srandom(s) drew different rotations than the second).  The reference's callers own that stream (seeded
 // drivers, compare_results.c:124-130), so every entry point parks it while HIP code runs.
+// Guards nest and may be entered from several host threads: only the outermost one swaps the state.
+static std::mutex g_rand_mu;
+static int g_rand_depth = 0;
+static char g_rand_scratch[256];
+static char *g_rand_saved = NULL;
 struct RandGuard {
-  char scratch[256];
-  char *saved;
-  RandGuard() { saved = initstate(1u, scratch, sizeof scratch); }
-  ~RandGuard() { setstate(saved); }
+  RandGuard() {
+    std::lock_guard<std::mutex> lk(g_rand_mu);
+    if (g_rand_depth++ == 0) g_rand_saved = initstate(1u, g_rand_scratch, sizeof g_rand_scratch);
+  }
+  ~RandGuard() {
+    std::lock_guard<std::mutex> lk(g_rand_mu);
+    if (--g_rand_depth == 0) setstate(g_rand_saved);
+  }
 };
 
 // ----------------------------------------------------------------------------- device lifecycle
@@ -608,6 +619,14 @@ extern "C" long annhip_stage1_finalize(annhip_index *ix, size_t Q, const ftype *
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipMemcpyAsync(&nflag, ix->d_fcount, sizeof(u32), hipMemcpyDeviceToHost, s));
   HIPCHECK(hipStreamSynchronize(s));
+  if (nflag > 1) {
+    // finalize1 appends with an atomic, so the order is arbitrary; every rank of a sharded host must see the
+    // SAME list (row i of the min-reduced distance rows has to be the same query everywhere): sort it.
+    std::vector<u32> fl(nflag);
+    HIPCHECK(hipMemcpy(fl.data(), flagged_dev, sizeof(u32) * nflag, hipMemcpyDeviceToHost));
+    std::sort(fl.begin(), fl.end());
+    HIPCHECK(hipMemcpy(flagged_dev, fl.data(), sizeof(u32) * nflag, hipMemcpyHostToDevice));
+  }
   ix->exact_queries += nflag;
   return (long)nflag;
 }

@@ -66,7 +66,8 @@ void annhip_stage1_local(annhip_index *ix, size_t ycnt, const ftype *y_dev, int 
                          uint32_t *nvalid_dev);
 /* 3. after the caller merged all devices' candidates into the k+1 globally best (same format):
  *    writes top_id u32[ycnt][k]/top_dist and the list of queries that need the exact path.
- *    Returns their count (synchronises). flagged_dev must hold ycnt entries.                             */
+ *    Returns their count (synchronises). flagged_dev must hold ycnt entries; the list is ascending, so it is
+ *    identical on every device of a sharded host.                                                        */
 long annhip_stage1_finalize(annhip_index *ix, size_t ycnt, const ftype *cand_dist_dev,
                             const uint32_t *cand_id_dev, const uint32_t *nvalid_dev,
                             uint32_t *top_id_dev, ftype *top_dist_dev, uint32_t *flagged_dev);

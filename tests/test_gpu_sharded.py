@@ -1,0 +1,125 @@
+"""GPU: the row-sharded kernels (owned-range filtering, +inf for foreign slots, per-shard candidates) and the
+sharded orchestration, with G shard indexes living on the ONE GPU of the test box.  Each shard runs in its own
+thread; ThreadDist is an in-process stand-in for the subset of torch.distributed that sharded.py uses."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+import approximatenn_amd as A
+from approximatenn_amd.sharded import ShardedQuery
+from oracle import oracle_py as O
+from tests.util import bits_equal, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+class ThreadDist:
+    class ReduceOp:
+        MIN = "min"
+
+    def __init__(self, world):
+        self.world, self.bar, self.slots, self.tl = world, threading.Barrier(world), [None] * world, threading.local()
+
+    def is_initialized(self):
+        return True
+
+    def get_world_size(self, group=None):
+        return self.world
+
+    def get_backend(self, group=None):
+        return "threads"
+
+    def all_gather(self, outs, t, group=None):
+        self.slots[self.tl.rank] = t
+        self.bar.wait()
+        for o, s in zip(outs, self.slots):
+            o.copy_(s)
+        torch.cuda.synchronize()
+        self.bar.wait()
+
+    def all_reduce(self, t, op=None, group=None):
+        self.slots[self.tl.rank] = t.clone()
+        self.bar.wait()
+        res = self.slots[0]
+        for s in self.slots[1:]:
+            res = torch.minimum(res, s)
+        torch.cuda.synchronize()
+        self.bar.wait()
+        t.copy_(res)
+        self.bar.wait()
+
+
+def _run_sharded(prec, save_arrays, pts, y, world, alias=False):
+    save = A.Save.from_dict(prec, save_arrays)
+    td = ThreadDist(world)
+    results, errors = [None] * world, []
+    yt = torch.from_numpy(np.ascontiguousarray(y)).cuda()
+
+    def work(rank):
+        try:
+            td.tl.rank = rank
+            lo, hi = (len(pts) * rank) // world, (len(pts) * (rank + 1)) // world
+            ix = A.Index.from_save(save, torch.from_numpy(np.ascontiguousarray(pts[lo:hi])).cuda(), lo, hi)
+            sq = ShardedQuery(ix, td)
+            ids, dd = sq.query(yt, alias=alias)
+            torch.cuda.synchronize()
+            results[rank] = (ids.cpu().numpy().astype(np.uint64), dd.cpu().numpy(), sq.last_exact)
+            ix.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            td.bar.abort()
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
+    return results
+
+
+@pytest.mark.parametrize("name,world", [("pow2_d128_f32", 2), ("pow2_d128_f64", 3), ("defaults_d80_f32", 2),
+                                        ("pow2_d32_f32", 4), ("k17_d100_f64", 2), ("few_candidates_f32", 2)])
+def test_sharded_on_one_gpu_matches_golden(name, world):
+    g = load_golden(name)
+    for ids, dd, _ in _run_sharded(g["prec"], g["save"], g["points"], g["y"], world):
+        assert np.array_equal(ids, g["query_ids"]) and bits_equal(dd, g["query_dists"])
+
+
+def _dup_dataset(prec, n_half, d, k, T, Q):
+    orc = O.CpuBackend(prec, "oracle")
+    O.srandom(321)
+    orc.rand_norm_reset()
+    half = orc.gen_rand(n_half * d).reshape(n_half, d)
+    pts = np.ascontiguousarray(np.concatenate([half, half]))   # every point twice => ties between different ids
+    y = orc.gen_rand(Q * d).reshape(Q, d)
+    O.srandom(17)
+    o_ids, o_d, o_save = orc.precomp(pts, k, T)
+    return orc, pts, y, o_ids, o_d, o_save
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_ties_take_the_exact_path_and_still_match(prec):
+    orc, pts, y, o_ids, o_d, o_save = _dup_dataset(prec, 700, 32, 6, 4, 90)
+    O.srandom(17)
+    ids, dists, save = A.precomp(pts, 6, 4)
+    try:
+        assert np.array_equal(ids, o_ids) and bits_equal(dists, o_d)
+        want = orc.query(o_save, pts, y)
+        got = A.query(save, pts, y)
+        assert np.array_equal(got[0], want[0]) and bits_equal(got[1], want[1])
+        ix = A.Index.from_save(save, pts)
+        r_ids, r_d, nex = ix.query(torch.from_numpy(y).cuda())
+        assert nex > len(y) // 2, "duplicated points must trip the tie test for most queries (got %d)" % nex
+        ix.close()
+        for s_ids, s_d, s_ex in _run_sharded(prec, o_save, pts, y, 2):
+            assert np.array_equal(s_ids, want[0]) and bits_equal(s_d, want[1]) and s_ex > 0
+    finally:
+        A._lib.load(prec).annhip_cache_clear()
+        save.free()
+
+
+def test_sharded_alias_query():
+    g = load_golden("pow2_d64_f32")
+    qa = len(g["alias_ids"])
+    for ids, dd, _ in _run_sharded("f32", g["save"], g["points"], g["points"][:qa], 2, alias=True):
+        assert np.array_equal(ids, g["alias_ids"]) and bits_equal(dd, g["alias_dists"])

@@ -1,0 +1,70 @@
+"""The point-sharded multi-rank orchestration (approximatenn_amd/sharded.py) under gloo on CPU, world_size 2 and 3,
+with the oracle-backed CpuShardEngine standing in for the per-shard HIP kernels.  Result on every rank must be
+bit-identical to the reference's single-device answer (golden vectors)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from approximatenn_amd.sharded import ShardedQuery
+from oracle import oracle_py as O
+from tests.cpu_engine import CpuShardEngine
+from tests.util import bits_equal, load_golden
+
+
+def _bounds(n, world, rank):
+    return (n * rank) // world, (n * (rank + 1)) // world
+
+
+def _tie_case():
+    """Every point exists twice (two ids, identical coordinates): ties between different ids everywhere,
+    so nearly every query is rejected by the selection proof and takes the exact, min-all-reduced path."""
+    orc = O.CpuBackend("f32", "oracle")
+    O.srandom(99)
+    orc.rand_norm_reset()
+    half = orc.gen_rand(150 * 16).reshape(150, 16)
+    pts = np.ascontiguousarray(np.concatenate([half, half]))
+    y = orc.gen_rand(12 * 16).reshape(12, 16)
+    O.srandom(5)
+    _, _, save = orc.precomp(pts, 4, 3)
+    ids, dd = orc.query(save, pts, y)
+    return pts, y, save, ids, dd
+
+
+def _worker(rank, world, port, case):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        if case == "ties":
+            pts, y, save, want_ids, want_d = _tie_case()
+            prec = "f32"
+        else:
+            g = load_golden(case)
+            pts, y, save, want_ids, want_d, prec = g["points"], g["y"], g["save"], g["query_ids"], g["query_dists"], g["prec"]
+        lo, hi = _bounds(len(pts), world, rank)
+        eng = CpuShardEngine(save, pts, lo, hi, prec)
+        sq = ShardedQuery(eng, dist)
+        ids, dd = sq.query(torch.from_numpy(np.ascontiguousarray(y)))
+        assert np.array_equal(ids.numpy().astype(np.uint64), want_ids), "rank %d ids" % rank
+        assert bits_equal(dd.numpy(), want_d), "rank %d dists" % rank
+        if case == "ties":
+            assert sq.last_exact > 0
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,case", [(2, "tiny_appendixA_f32"), (2, "odd_everything_f32"), (3, "few_candidates_f64"),
+                                        (2, "k17_d100_f64"), (2, "ties")])
+def test_sharded_query_matches_reference(world, case):
+    port = 29500 + (os.getpid() + hash(case)) % 2000
+    mp.spawn(_worker, args=(world, port, case), nprocs=world, join=True)
+
+
+def test_single_rank_engine_matches_reference():
+    g = load_golden("one_try_one_query_f32")
+    eng = CpuShardEngine(g["save"], g["points"], 0, g["cfg"]["n"], "f32")
+    ids, dd = ShardedQuery(eng, None).query(torch.from_numpy(g["y"]))
+    assert np.array_equal(ids.numpy().astype(np.uint64), g["query_ids"]) and bits_equal(dd.numpy(), g["query_dists"])
