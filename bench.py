@@ -37,11 +37,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=10_000_000)
-    ap.add_argument("--d", type=int, default=128)
-    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--points", dest="n", type=int, default=10_000_000)
+    ap.add_argument("--dim", dest="d", type=int, default=128)
+    ap.add_argument("--knn", dest="k", type=int, default=10)
     ap.add_argument("--tries", type=int, default=10)
-    ap.add_argument("--q", type=int, default=10_000, help="queries per GPU per step")
+    ap.add_argument("--queries", dest="q", type=int, default=10_000, help="queries per GPU per step")
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")

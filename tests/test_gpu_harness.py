@@ -1,0 +1,33 @@
+"""GPU: the C harnesses (tests/harness) -- the reference-shaped drivers run against the HIP library through
+the plain C surface of include/ann.h, with the oracle as the CPU side.  compare_results exits non-zero on any
+id difference or distance violation."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+H = os.path.join(os.path.dirname(os.path.abspath(__file__)), "harness")
+
+
+def _run(args):
+    out = subprocess.run(args, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    return out.stdout
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_compare_results_precomp_mode(prec):
+    out = _run([os.path.join(H, "compare_results_" + prec), "-o", "2", "-S", "41"])     # reference defaults: n=1000 d=80 k=10
+    assert "Average diffs for comp: 0" in out and "PASS" in out and "0 not bit-identical" in out
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_compare_results_query_mode(prec):
+    out = _run([os.path.join(H, "compare_results_" + prec), "-n", "5000", "-d", "64", "-y", "200", "-o", "3", "-S", "42"])
+    assert "Average diffs for query: 0" in out and "PASS" in out and "0 not bit-identical" in out
+
+
+def test_time_results_runs_config1_shape():
+    out = _run([os.path.join(H, "time_results_f32"), "-n", "20000", "-d", "32", "-k", "10", "-y", "500", "-o", "3", "-S", "7"])
+    assert "queries/s" in out and "on CPU, oracle" in out
