@@ -146,6 +146,7 @@ static unsigned grid_for(size_t work, unsigned block, unsigned cap = 1u << 20) {
   return (unsigned)g;
 }
 
+#define ANN_NCOUNTERS (8 + 64 * 8)
 struct EventPair {
   hipEvent_t a, b;
 };
@@ -167,12 +168,12 @@ struct annhip_index {
   // workspace of annhip_query
   DevBuf codes, cand_d, cand_i, nvt, nvo, top_i, top_d, flist, xids, xd, r2i, r2d, out_i, out_d;
   u32 *d_fcount = NULL;
-  unsigned long long *d_rows = NULL;  // [0] stage-1 gathered rows, [1] rows kernels
+  unsigned long long *d_rows = NULL;  // [0] stage-1 gathered rows, [2] exact-path queries, [8..8+512) rows kernels (64 padded shards)
   // measurement
   bool profile = false;
   std::vector<EventPair> ev_used, ev_free;
   double s1_ms = 0;
-  double s1_launches = 0, exact_queries = 0, queries = 0;
+  double s1_launches = 0, queries = 0;
 };
 
 static QParams make_params(const annhip_index *ix) {
@@ -214,8 +215,8 @@ static void finish_geometry(annhip_index *ix) {
   HIPCHECK(hipMemcpy(ix->d_tries, ix->h_tries.data(), sizeof(TryInfo) * ix->T, hipMemcpyHostToDevice));
   if (!ix->d_fcount) ix->d_fcount = dev_alloc<u32>(4);
   if (!ix->d_rows) {
-    ix->d_rows = dev_alloc<unsigned long long>(4);
-    HIPCHECK(hipMemset(ix->d_rows, 0, 4 * sizeof(unsigned long long)));
+    ix->d_rows = dev_alloc<unsigned long long>(ANN_NCOUNTERS);
+    HIPCHECK(hipMemset(ix->d_rows, 0, ANN_NCOUNTERS * sizeof(unsigned long long)));
   }
 }
 
@@ -373,15 +374,35 @@ static bool d_is_fast(size_t d) {
   return probe > 0;
 }
 
+template <typename K>
+static void allow_lds(K kernel, size_t bytes) {
+  if (bytes > 160 * 1024) die("row too long for the LDS of one CU");
+  if (bytes > 48 * 1024)
+    HIPCHECK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+}
+
 static void launch_codes(const QParams &P, size_t Q, const FT *y, u32 *codes, hipStream_t s) {
   const int wpb = 4;
   const size_t items = Q * (size_t)P.T;
   if (!items) return;
-  const unsigned grid = (unsigned)((items + wpb - 1) / wpb);
-  const size_t smem = d_is_fast(P.d) ? 0 : sizeof(FT) * wpb * 2 * (size_t)P.d;
-#define CALL(DD) hipLaunchKernelGGL(codes_kernel<DD>, dim3(grid), dim3(64 * wpb), smem, s, P, (int)Q, y, codes)
-  ANN_DISPATCH_D(P.d, CALL);
+  if (d_is_fast(P.d)) {  // workgroup = (try, run of queries); the try's projection rows live in LDS
+    const size_t smem = sizeof(FT) * (size_t)P.ds * P.d;
+    const dim3 grid((unsigned)((Q + ANN_CODES_QPB - 1) / ANN_CODES_QPB), (unsigned)P.T);
+#define CALL(DD)                                                                                      \
+  do {                                                                                                \
+    if (DD > 0) {                                                                                     \
+      allow_lds(codes_kernel<DD>, smem);                                                              \
+      hipLaunchKernelGGL(codes_kernel<DD>, grid, dim3(64 * wpb), smem, s, P, (int)Q, y, codes);       \
+    }                                                                                                 \
+  } while (0)
+    ANN_DISPATCH_D(P.d, CALL);
 #undef CALL
+  } else {
+    const unsigned grid = (unsigned)((items + wpb - 1) / wpb);
+    const size_t smem = sizeof(FT) * wpb * 2 * (size_t)P.d;
+    allow_lds(codes_kernel<0>, smem);
+    hipLaunchKernelGGL(codes_kernel<0>, dim3(grid), dim3(64 * wpb), smem, s, P, (int)Q, y, codes);
+  }
   HIPCHECK(hipGetLastError());
 }
 
@@ -408,11 +429,13 @@ static size_t stage1_lds_bytes(const QParams &P, int W, int K1, int cap) {
   return b;
 }
 
-template <typename K>
-static void allow_lds(K kernel, size_t bytes) {
-  if (bytes > 160 * 1024) die("row too long for the LDS of one CU");
-  if (bytes > 48 * 1024)
-    HIPCHECK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+__global__ void sum_u32_kernel(size_t count, const u32 *__restrict__ v, unsigned long long *out) {
+  unsigned long long acc = 0;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (size_t)gridDim.x * blockDim.x)
+    acc += v[e];
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) acc += __shfl_xor(acc, s);
+  if (lane_id() == 0) atomicAdd(out, acc);
 }
 
 static void launch_stage1(annhip_index *ix, const QParams &P, size_t Q, const FT *y, int alias,
@@ -444,12 +467,14 @@ static void launch_stage1(annhip_index *ix, const QParams &P, size_t Q, const FT
   if (prof) {
     HIPCHECK(hipEventRecord(ev.b, s));
     ix->ev_used.push_back(ev);
+    // gathered-row statistics only while measuring: one small reduction kernel, outside the event bracket
+    sum_u32_kernel<<<grid_for(Q, 256, 64), 256, 0, s>>>(Q, nvo, ix->d_rows);
   }
   if (ix) ix->s1_launches += 1;
 }
 
-static size_t rows_lds_bytes(const QParams &P) {
-  size_t b = 2 * sizeof(u32) * ANN_RD_CHUNK + sizeof(TryInfo) * (size_t)P.T + sizeof(u32) * (size_t)P.T + 16;
+static size_t rows_lds_bytes(const QParams &P, u32 chunk) {
+  size_t b = 2 * sizeof(u32) * (size_t)chunk + sizeof(TryInfo) * (size_t)P.T + sizeof(u32) * (size_t)P.T + 16;
   b = (b + 15) & ~(size_t)15;
   if (!d_is_fast(P.d)) b += sizeof(FT) * (size_t)P.d * (1 + 4);
   return b;
@@ -458,14 +483,17 @@ static size_t rows_lds_bytes(const QParams &P) {
 template <int MODE>
 static void launch_rows(const QParams &P, size_t Q, const FT *y, int alias, const u32 *codes, const u32 *qidx,
                         u32 xbase, size_t nq, u32 len, const u32 *top_i, const FT *top_d, u32 *ids, FT *dist,
-                        unsigned long long *rows_done, hipStream_t s) {
+                        unsigned long long *rows_done, hipStream_t s, const u32 *live_rows = NULL) {
   if (!nq) return;
-  const size_t smem = rows_lds_bytes(P);
+  const u32 chunk = len < ANN_RD_CHUNK ? ((len + 63u) & ~63u) : ANN_RD_CHUNK;  // LDS lists sized to the row
+  const size_t smem = rows_lds_bytes(P, chunk);
+  // short rows (stage 2 at small k): fewer waves per row, more rows resident per CU
+  const unsigned block = len <= 128 ? 128 : 256;
 #define CALL(DD)                                                                                         \
   do {                                                                                                   \
     allow_lds(row_dists_kernel<DD, MODE>, smem);                                                         \
-    hipLaunchKernelGGL((row_dists_kernel<DD, MODE>), dim3((unsigned)nq), dim3(256), smem, s, P, (int)Q, y, \
-                       alias, codes, qidx, xbase, len, top_i, top_d, ids, dist, rows_done);              \
+    hipLaunchKernelGGL((row_dists_kernel<DD, MODE>), dim3((unsigned)nq), dim3(block), smem, s, P, (int)Q, y, \
+                       alias, codes, qidx, xbase, len, top_i, top_d, ids, dist, rows_done, live_rows, chunk); \
   } while (0)
   ANN_DISPATCH_D(P.d, CALL);
 #undef CALL
@@ -475,7 +503,7 @@ static void launch_rows(const QParams &P, size_t Q, const FT *y, int alias, cons
 // network + rdups + network on nq rows of reference length L, `len` stored entries, row stride in_stride
 static void launch_exact_select(u32 L, u32 len, u32 in_stride, int k, size_t nq, u32 *ids, FT *dist,
                                 const u32 *qidx, u32 xbase, u32 *out_i, FT *out_d, int ostride, int ooff,
-                                hipStream_t s) {
+                                hipStream_t s, const u32 *live_rows = NULL) {
   if (!nq) return;
   const int lk = ann_lg(L);
   unsigned npairs = 8u << (lk > 4 ? lk - 4 : 0);
@@ -484,47 +512,56 @@ static void launch_exact_select(u32 L, u32 len, u32 in_stride, int k, size_t nq,
   const size_t smem = (size_t)len * (sizeof(FT) + sizeof(u32));
   if (smem <= 60 * 1024)
     hipLaunchKernelGGL(exact_select_kernel<true>, dim3((unsigned)nq), dim3(block), smem, s, L, len, in_stride, k,
-                       ids, dist, qidx, xbase, out_i, out_d, ostride, ooff);
+                       ids, dist, qidx, xbase, out_i, out_d, ostride, ooff, live_rows);
   else
     hipLaunchKernelGGL(exact_select_kernel<false>, dim3((unsigned)nq), dim3(block), 0, s, L, len, in_stride, k,
-                       ids, dist, qidx, xbase, out_i, out_d, ostride, ooff);
+                       ids, dist, qidx, xbase, out_i, out_d, ostride, ooff, live_rows);
   HIPCHECK(hipGetLastError());
 }
 
-__global__ void sum_u32_kernel(size_t count, const u32 *__restrict__ v, unsigned long long *out) {
-  unsigned long long acc = 0;
-  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (size_t)gridDim.x * blockDim.x)
-    acc += v[e];
-#pragma unroll
-  for (int s = 32; s >= 1; s >>= 1) acc += __shfl_xor(acc, s);
-  if (lane_id() == 0) atomicAdd(out, acc);
-}
-
 // finalize + exact fallback for the queries finalize1 rejected.  The top-k lands in top_i/top_d
-// (row stride ostride, column offset ooff).  Returns the number of exact-path queries.
+// (row stride ostride, column offset ooff).  device_driven: no host read-back -- the exact-path kernels are
+// launched over the worst case (every query rejected) and rows beyond the device-side count exit at once;
+// used when the worst-case workspace is affordable (query batches).  Otherwise (precomp: millions of rows) the
+// count is read back and the exact path runs in bounded chunks.  Returns the number of exact-path rows when it
+// is known on the host (-1 when device-driven).
 static long finalize_and_fallback(annhip_index *ix, const QParams &P, size_t Q, const FT *y, int alias,
                                   const u32 *codes, int mode, const FT *cand_d, const u32 *cand_i,
                                   const u32 *nvt, u32 *top_i, FT *top_d, int ostride, int ooff, DevBuf &flist,
                                   DevBuf &xids, DevBuf &xd, u32 *d_fcount, unsigned long long *rows_done,
-                                  hipStream_t s) {
+                                  unsigned long long *exact_total, bool device_driven, hipStream_t s) {
   const int K1 = P.k + 1;
   u32 nflag = 0;
   u32 *fl = (u32 *)flist.need(sizeof(u32) * Q);
+  const size_t row_bytes = (size_t)P.Lc1 * (sizeof(FT) + sizeof(u32));
+  size_t chunk = ((size_t)1 << 30) / (row_bytes ? row_bytes : 1);
+  if (chunk < 1) chunk = 1;
   if (mode == 0) {
     HIPCHECK(hipMemsetAsync(d_fcount, 0, sizeof(u32), s));
     hipLaunchKernelGGL(finalize1_kernel, dim3(grid_for(Q, 256, 1u << 30)), dim3(256), 0, s, (int)Q, P.k, K1, P.L1,
-                       P.P1, cand_d, cand_i, nvt, top_i, top_d, ostride, ooff, fl, d_fcount);
+                       P.P1, cand_d, cand_i, nvt, top_i, top_d, ostride, ooff, fl, d_fcount, exact_total);
     HIPCHECK(hipGetLastError());
+    if (device_driven && Q <= chunk) {
+      u32 *ids = (u32 *)xids.need(sizeof(u32) * Q * P.Lc1);
+      FT *dist = (FT *)xd.need(sizeof(FT) * Q * P.Lc1);
+      launch_rows<MODE_TABLE>(P, Q, y, alias, codes, fl, 0, Q, P.Lc1, NULL, NULL, ids, dist, rows_done, s, d_fcount);
+      launch_exact_select(P.L1, P.Lc1, P.Lc1, P.k, Q, ids, dist, fl, 0, top_i, top_d, ostride, ooff, s, d_fcount);
+      return -1;
+    }
     HIPCHECK(hipMemcpyAsync(&nflag, d_fcount, sizeof(u32), hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
   } else {
     nflag = (u32)Q;
+    if (exact_total) {
+      unsigned long long add = Q, cur = 0;
+      HIPCHECK(hipMemcpyAsync(&cur, exact_total, sizeof cur, hipMemcpyDeviceToHost, s));
+      HIPCHECK(hipStreamSynchronize(s));
+      cur += add;
+      HIPCHECK(hipMemcpyAsync(exact_total, &cur, sizeof cur, hipMemcpyHostToDevice, s));
+      HIPCHECK(hipStreamSynchronize(s));
+    }
   }
-  // exact path in bounded chunks of rows
-  const size_t row_bytes = (size_t)P.Lc1 * (sizeof(FT) + sizeof(u32));
-  size_t chunk = ((size_t)1 << 30) / (row_bytes ? row_bytes : 1);
-  if (chunk < 1) chunk = 1;
-  for (size_t q0 = 0; q0 < nflag; q0 += chunk) {
+  for (size_t q0 = 0; q0 < nflag; q0 += chunk) {  // exact path in bounded chunks of rows
     const size_t nq = std::min(chunk, (size_t)nflag - q0);
     u32 *ids = (u32 *)xids.need(sizeof(u32) * nq * P.Lc1);
     FT *dist = (FT *)xd.need(sizeof(FT) * nq * P.Lc1);
@@ -532,7 +569,6 @@ static long finalize_and_fallback(annhip_index *ix, const QParams &P, size_t Q, 
     launch_rows<MODE_TABLE>(P, Q, y, alias, codes, qidx, (u32)q0, nq, P.Lc1, NULL, NULL, ids, dist, rows_done, s);
     launch_exact_select(P.L1, P.Lc1, P.Lc1, P.k, nq, ids, dist, qidx, (u32)q0, top_i, top_d, ostride, ooff, s);
   }
-  if (ix) ix->exact_queries += nflag;
   return (long)nflag;
 }
 
@@ -559,10 +595,10 @@ extern "C" long annhip_query(annhip_index *ix, size_t Q, const ftype *y_dev, int
     nvt = (u32 *)ix->nvt.need(sizeof(u32) * Q);
     u32 *nvo = (u32 *)ix->nvo.need(sizeof(u32) * Q);
     launch_stage1(ix, P, Q, y, alias, codes, cand_d, cand_i, nvt, nvo, s);
-    sum_u32_kernel<<<grid_for(Q, 256, 64), 256, 0, s>>>(Q, nvo, ix->d_rows);
   }
+  unsigned long long *rows_ctr = ix->profile ? ix->d_rows + 8 : NULL;
   long nflag = finalize_and_fallback(ix, P, Q, y, alias, codes, mode, cand_d, cand_i, nvt, top_i, top_d, k, 0,
-                                     ix->flist, ix->xids, ix->xd, ix->d_fcount, ix->d_rows + 1, s);
+                                     ix->flist, ix->xids, ix->xd, ix->d_fcount, rows_ctr, ix->d_rows + 2, true, s);
   // stage 2 (det_results second half, alg.c:314-327)
   u32 *out_i = (u32 *)ix->out_i.need(sizeof(u32) * Q * k);
   FT *out_d = dists_dev ? reinterpret_cast<FT *>(dists_dev) : (FT *)ix->out_d.need(sizeof(FT) * Q * k);
@@ -573,7 +609,7 @@ extern "C" long annhip_query(annhip_index *ix, size_t Q, const ftype *y_dev, int
     const size_t nq = std::min(chunk, Q - q0);
     u32 *r2i = (u32 *)ix->r2i.need(sizeof(u32) * nq * P.Lc2);
     FT *r2d = (FT *)ix->r2d.need(sizeof(FT) * nq * P.Lc2);
-    launch_rows<MODE_GRAPH>(P, Q, y, alias, NULL, NULL, (u32)q0, nq, P.Lc2, top_i, top_d, r2i, r2d, ix->d_rows + 1, s);
+    launch_rows<MODE_GRAPH>(P, Q, y, alias, NULL, NULL, (u32)q0, nq, P.Lc2, top_i, top_d, r2i, r2d, rows_ctr, s);
     launch_exact_select(P.L2, P.Lc2, P.Lc2, k, nq, r2i, r2d, NULL, (u32)q0, out_i, out_d, k, 0, s);
   }
   widen_ids_kernel<<<grid_for(Q * k, 256, 1u << 30), 256, 0, s>>>(Q * k, out_i, ids_dev);
@@ -594,7 +630,6 @@ extern "C" void annhip_stage1_local(annhip_index *ix, size_t Q, const ftype *y_d
   u32 *nvo = (u32 *)ix->nvo.need(sizeof(u32) * Q);
   launch_stage1(ix, P, Q, reinterpret_cast<const FT *>(y_dev), alias, codes_dev, reinterpret_cast<FT *>(cand_dist_dev),
                 cand_id_dev, nvalid_dev, nvo, ix->stream);
-  sum_u32_kernel<<<grid_for(Q, 256, 64), 256, 0, ix->stream>>>(Q, nvo, ix->d_rows);
   ix->queries += (double)Q;
 }
 
@@ -609,13 +644,16 @@ extern "C" long annhip_stage1_finalize(annhip_index *ix, size_t Q, const ftype *
     for (size_t i = 0; i < Q; i++) all[i] = (u32)i;
     HIPCHECK(hipMemcpyAsync(flagged_dev, all.data(), sizeof(u32) * Q, hipMemcpyHostToDevice, s));
     HIPCHECK(hipStreamSynchronize(s));
-    ix->exact_queries += (double)Q;
+    unsigned long long cur = 0;
+    HIPCHECK(hipMemcpy(&cur, ix->d_rows + 2, sizeof cur, hipMemcpyDeviceToHost));
+    cur += Q;
+    HIPCHECK(hipMemcpy(ix->d_rows + 2, &cur, sizeof cur, hipMemcpyHostToDevice));
     return (long)Q;
   }
   HIPCHECK(hipMemsetAsync(ix->d_fcount, 0, sizeof(u32), s));
   hipLaunchKernelGGL(finalize1_kernel, dim3(grid_for(Q, 256, 1u << 30)), dim3(256), 0, s, (int)Q, P.k, P.k + 1, P.L1,
                      P.P1, reinterpret_cast<const FT *>(cand_dist_dev), cand_id_dev, nvalid_dev, top_id_dev,
-                     reinterpret_cast<FT *>(top_dist_dev), P.k, 0, flagged_dev, ix->d_fcount);
+                     reinterpret_cast<FT *>(top_dist_dev), P.k, 0, flagged_dev, ix->d_fcount, ix->d_rows + 2);
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipMemcpyAsync(&nflag, ix->d_fcount, sizeof(u32), hipMemcpyDeviceToHost, s));
   HIPCHECK(hipStreamSynchronize(s));
@@ -627,7 +665,6 @@ extern "C" long annhip_stage1_finalize(annhip_index *ix, size_t Q, const ftype *
     std::sort(fl.begin(), fl.end());
     HIPCHECK(hipMemcpy(flagged_dev, fl.data(), sizeof(u32) * nflag, hipMemcpyHostToDevice));
   }
-  ix->exact_queries += nflag;
   return (long)nflag;
 }
 
@@ -636,7 +673,7 @@ extern "C" void annhip_stage1_rows(annhip_index *ix, size_t Q, const ftype *y_de
                                    uint32_t *ids_dev, ftype *dist_dev) {
   const QParams P = make_params(ix);
   launch_rows<MODE_TABLE>(P, Q, reinterpret_cast<const FT *>(y_dev), alias, codes_dev, qidx_dev, 0, nq, P.Lc1, NULL,
-                          NULL, ids_dev, reinterpret_cast<FT *>(dist_dev), ix->d_rows + 1, ix->stream);
+                          NULL, ids_dev, reinterpret_cast<FT *>(dist_dev), ix->profile ? ix->d_rows + 8 : NULL, ix->stream);
 }
 
 extern "C" void annhip_stage2_rows(annhip_index *ix, size_t Q, const ftype *y_dev, int alias,
@@ -645,7 +682,7 @@ extern "C" void annhip_stage2_rows(annhip_index *ix, size_t Q, const ftype *y_de
   const QParams P = make_params(ix);
   launch_rows<MODE_GRAPH>(P, Q, reinterpret_cast<const FT *>(y_dev), alias, NULL, NULL, 0, Q, P.Lc2, top_id_dev,
                           reinterpret_cast<const FT *>(top_dist_dev), ids_dev, reinterpret_cast<FT *>(dist_dev),
-                          ix->d_rows + 1, ix->stream);
+                          ix->profile ? ix->d_rows + 8 : NULL, ix->stream);
 }
 
 extern "C" void annhip_exact_select(annhip_index *ix, int stage, size_t nq, uint32_t *ids_dev, ftype *dist_dev,
@@ -673,12 +710,14 @@ extern "C" void annhip_stats(annhip_index *ix, double out[8], int reset) {
     ix->ev_free.push_back(e);
   }
   ix->ev_used.clear();
-  unsigned long long rows[4] = {0, 0, 0, 0};
+  unsigned long long rows[ANN_NCOUNTERS];
   HIPCHECK(hipMemcpy(rows, ix->d_rows, sizeof rows, hipMemcpyDeviceToHost));
-  out[0] = ix->s1_launches, out[1] = ix->s1_ms, out[2] = (double)rows[0], out[3] = (double)rows[1];
-  out[4] = ix->exact_queries, out[5] = ix->queries, out[6] = out[7] = 0;
+  unsigned long long other = 0;
+  for (int i = 0; i < 64; i++) other += rows[8 + i * 8];
+  out[0] = ix->s1_launches, out[1] = ix->s1_ms, out[2] = (double)rows[0], out[3] = (double)other;
+  out[4] = (double)rows[2], out[5] = ix->queries, out[6] = out[7] = 0;
   if (reset) {
-    ix->s1_launches = ix->s1_ms = ix->exact_queries = ix->queries = 0;
+    ix->s1_launches = ix->s1_ms = ix->queries = 0;
     HIPCHECK(hipMemset(ix->d_rows, 0, sizeof rows));
   }
 }
@@ -819,8 +858,8 @@ extern "C" annhip_index *annhip_precomp_index(size_t n, size_t k, size_t d, cons
   ix->h_tries.resize(T);
   ix->d_tabs.resize(T);
   ix->d_fcount = dev_alloc<u32>(4);
-  ix->d_rows = dev_alloc<unsigned long long>(4);
-  HIPCHECK(hipMemset(ix->d_rows, 0, 4 * sizeof(unsigned long long)));
+  ix->d_rows = dev_alloc<unsigned long long>(ANN_NCOUNTERS);
+  HIPCHECK(hipMemset(ix->d_rows, 0, ANN_NCOUNTERS * sizeof(unsigned long long)));
   TryInfo *solo = dev_alloc<TryInfo>(1);
   DevBuf cand_d, cand_i, nvt, nvo, flist, xids, xd;
   for (int t = 0; t < T; t++) {
@@ -863,7 +902,7 @@ extern "C" annhip_index *annhip_precomp_index(size_t n, size_t k, size_t d, cons
       launch_stage1(NULL, P, n, pts, 1, codes[t], cd, ci, nv, no, s);
     }
     finalize_and_fallback(NULL, P, n, pts, 1, codes[t], mode, cd, ci, nv, merged_i, merged_d, (int)W, (int)(t * k),
-                          flist, xids, xd, ix->d_fcount, NULL, s);
+                          flist, xids, xd, ix->d_fcount, NULL, NULL, false, s);
     HIPCHECK(hipStreamSynchronize(s));
     HIPCHECK(hipFree(codes[t]));
   }

@@ -111,12 +111,13 @@ def main():
         step(batches[i])
     torch.cuda.synchronize()
     ix.stats(reset=True)
-    ix.profile(True)
+    ix.profile(os.environ.get("ANN_BENCH_NO_EVENTS") != "1")
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(batches[args.warmup + i])
+    submit_s = time.perf_counter() - t0  # host time to enqueue K steps (the path is asynchronous on one GPU)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -147,7 +148,8 @@ def main():
             "config": {"workload": "cfg3: N=%d d=%d k=%d tries=%d Q=%d/step float, randn points+queries" % (n, d, k, T, Q),
                        "points_sharding": "rows/%d" % world, "d_short": ix.d_short, "L1": ix.L1, "P1": ix.P1,
                        "L2": ix.L2, "P2": ix.P2, "sum_par_maxes": ix.sum_pm, "precomp_s": round(precomp_s, 2),
-                       "exact_path_queries_per_step": round(st["exact_queries"] / args.steps, 2)},
+                       "exact_path_queries_per_step": round(st["exact_queries"] / args.steps, 2),
+                       "host_submit_ms_per_step": round(submit_s / args.steps * 1e3, 4)},
             "roofline": roofline}
 
     # ---- CPU baseline + full-size parity sample (rank 0, single GPU only)

@@ -50,8 +50,10 @@ annhip_index *annhip_precomp_index(size_t n, size_t k, size_t d, const ftype *po
 /* ---- whole query on one device (alg.c:458-519) ------------------------------------------------- */
 /* y_dev: ftype[ycnt][d]; alias != 0: query x excludes point x (the y == points case, compute.cl:144-146).
  * mode 0: selection path with exact fallback; mode 1: exact path for every query.
- * ids_dev: size_t[ycnt][k], dists_dev: ftype[ycnt][k] (may be NULL).  Returns the number of queries that
- * took the exact path.  Asynchronous on the index's stream except for one 4-byte read-back. */
+ * ids_dev: size_t[ycnt][k], dists_dev: ftype[ycnt][k] (may be NULL).  Fully asynchronous on the index's
+ * stream (the exact fallback is driven by a device-side count, no host read-back); returns -1 in that case, or
+ * the number of exact-path queries when it is known on the host (mode 1, very large batches).  The running
+ * count is in annhip_stats(). */
 long annhip_query(annhip_index *ix, size_t ycnt, const ftype *y_dev, int alias, int mode,
                   size_t *ids_dev, ftype *dists_dev);
 
@@ -91,9 +93,10 @@ void annhip_widen_ids(annhip_index *ix, size_t count, const uint32_t *in_dev, si
 /* ---- measurement ---------------------------------------------------------------------------------- */
 /* profile != 0: bracket every stage1 launch with HIP events on the index's stream. */
 void annhip_profile(annhip_index *ix, int profile);
-/* out[0]=stage-1 launches, out[1]=their total ms (events), out[2]=rows gathered in stage 1 (owned valid
- * slots), out[3]=rows gathered in stage-2/exact rows kernels, out[4]=queries through the exact path,
- * out[5]=queries seen; counters accumulate since the last reset (reset != 0 clears them after reading). */
+/* out[0]=stage-1 launches, out[1]=their total ms (events; only while profiling), out[2]=rows gathered in stage 1
+ * (owned valid slots; only while profiling), out[3]=rows gathered in stage-2/exact rows kernels (only while
+ * profiling), out[4]=queries through the exact path, out[5]=queries seen; counters accumulate since the last
+ * reset (reset != 0 clears them after reading). */
 void annhip_stats(annhip_index *ix, double out[8], int reset);
 
 #ifdef __cplusplus

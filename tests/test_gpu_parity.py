@@ -105,6 +105,7 @@ def test_resident_index_device_tensors():
     pts = torch.from_numpy(g["points"]).cuda()
     ix = A.Index.from_save(save, pts)
     y = torch.from_numpy(g["y"]).cuda()
+    ix.profile(True)  # gathered-row statistics are only collected while profiling
     for mode in (0, 1):
         ids, dists, nex = ix.query(y, mode=mode)
         torch.cuda.synchronize()

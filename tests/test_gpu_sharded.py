@@ -108,8 +108,10 @@ def test_ties_take_the_exact_path_and_still_match(prec):
         got = A.query(save, pts, y)
         assert np.array_equal(got[0], want[0]) and bits_equal(got[1], want[1])
         ix = A.Index.from_save(save, pts)
-        r_ids, r_d, nex = ix.query(torch.from_numpy(y).cuda())
+        r_ids, r_d, _ = ix.query(torch.from_numpy(y).cuda())
+        nex = ix.stats()["exact_queries"]
         assert nex > len(y) // 2, "duplicated points must trip the tie test for most queries (got %d)" % nex
+        assert np.array_equal(r_ids.cpu().numpy().astype(np.uint64), want[0])
         ix.close()
         for s_ids, s_d, s_ex in _run_sharded(prec, o_save, pts, y, 2):
             assert np.array_equal(s_ids, want[0]) and bits_equal(s_d, want[1]) and s_ex > 0
