@@ -510,10 +510,11 @@ static void launch_exact_select(u32 L, u32 len, u32 in_stride, int k, size_t nq,
   unsigned block = npairs >= 256 ? 256 : ((npairs + 63) / 64) * 64;
   if (block < 64) block = 64;
   const size_t smem = (size_t)len * (sizeof(FT) + sizeof(u32));
-  if (smem <= 60 * 1024)
+  if (smem <= 150 * 1024) {  // the whole row in LDS (one CU has 160 KB); longer rows sort in place in HBM
+    allow_lds(exact_select_kernel<true>, smem);
     hipLaunchKernelGGL(exact_select_kernel<true>, dim3((unsigned)nq), dim3(block), smem, s, L, len, in_stride, k,
                        ids, dist, qidx, xbase, out_i, out_d, ostride, ooff, live_rows);
-  else
+  } else
     hipLaunchKernelGGL(exact_select_kernel<false>, dim3((unsigned)nq), dim3(block), 0, s, L, len, in_stride, k,
                        ids, dist, qidx, xbase, out_i, out_d, ostride, ooff, live_rows);
   HIPCHECK(hipGetLastError());
@@ -777,7 +778,8 @@ extern "C" annhip_index *annhip_precomp_index(size_t n, size_t k, size_t d, cons
   while (d_max < d) d_max <<= 1;
   if (ds > d_max) ds = d_max;
   check_limits(n, k, d, ds, tries);
-  if (2 * rot_len_before > d || 2 * rot_len_after > ds) die("rotation length exceeds dimension (rand_rot needs 2*len <= dim)");
+  if ((rots_before && 2 * rot_len_before > d) || (rots_after && 2 * rot_len_after > ds))
+    die("rotation length exceeds dimension (rand_rot needs 2*len <= dim; the reference divides by zero there)");
   const int T = tries;
   // Every transform is drawn up front, in the reference's order (alg.c:387-392, Q12), and BEFORE any HIP call:
   // these draws are the only use this path makes of the caller's random() stream.
