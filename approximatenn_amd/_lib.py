@@ -63,6 +63,7 @@ def load(prec="f32"):
     lib.annhip_query.argtypes = [vp, sz, vp, C.c_int, C.c_int, vp, vp]
     lib.annhip_codes.argtypes = [vp, sz, vp, u32p]
     lib.annhip_stage1_local.argtypes = [vp, sz, vp, C.c_int, u32p, vp, u32p, u32p]
+    lib.annhip_merge_candidates.argtypes = [vp, C.c_int, sz, vp, u32p, vp, u32p]
     lib.annhip_stage1_finalize.restype = C.c_long
     lib.annhip_stage1_finalize.argtypes = [vp, sz, vp, u32p, u32p, u32p, vp, u32p]
     lib.annhip_stage1_rows.argtypes = [vp, sz, vp, C.c_int, u32p, u32p, sz, u32p, vp]
@@ -87,6 +88,6 @@ def load(prec="f32"):
 EXPORTED = ["gpu_init", "gpu_cleanup", "register_cleanup", "query_gpu", "precomp_gpu", "annhip_precision",
             "annhip_index_create", "annhip_index_destroy", "annhip_index_info", "annhip_index_set_stream",
             "annhip_index_export", "annhip_index_reshard", "annhip_precomp_index", "annhip_query", "annhip_codes", "annhip_stage1_local",
-            "annhip_stage1_finalize", "annhip_stage1_rows", "annhip_stage2_rows", "annhip_exact_select",
+            "annhip_merge_candidates", "annhip_stage1_finalize", "annhip_stage1_rows", "annhip_stage2_rows", "annhip_exact_select",
             "annhip_widen_ids", "annhip_profile", "annhip_stats"]
 DISPATCH_EXPORTED = ["precomp", "query", "free_save"]

@@ -693,6 +693,16 @@ extern "C" void annhip_exact_select(annhip_index *ix, int stage, size_t nq, uint
                       out_id_dev, reinterpret_cast<FT *>(out_dist_dev), (int)ix->k, 0, ix->stream);
 }
 
+extern "C" void annhip_merge_candidates(annhip_index *ix, int ndev, size_t Q, const ftype *in_dist_dev,
+                                        const uint32_t *in_id_dev, ftype *out_dist_dev, uint32_t *out_id_dev) {
+  if (ndev < 1 || ndev > 16) die("annhip_merge_candidates supports 1..16 devices");
+  if (!Q) return;
+  hipLaunchKernelGGL(merge_candidates_kernel, dim3(grid_for(Q, 128, 1u << 30)), dim3(128), 0, ix->stream, ndev, (int)Q,
+                     (int)ix->k + 1, reinterpret_cast<const FT *>(in_dist_dev), in_id_dev,
+                     reinterpret_cast<FT *>(out_dist_dev), out_id_dev);
+  HIPCHECK(hipGetLastError());
+}
+
 extern "C" void annhip_widen_ids(annhip_index *ix, size_t count, const uint32_t *in_dev, size_t *out_dev) {
   if (!count) return;
   widen_ids_kernel<<<grid_for(count, 256, 1u << 30), 256, 0, ix->stream>>>(count, in_dev, out_dev);

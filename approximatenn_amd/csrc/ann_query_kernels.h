@@ -484,6 +484,39 @@ __global__ __launch_bounds__(256) void exact_select_kernel(u32 L, u32 len, u32 i
   }
 }
 
+// ------------------------------------------------------------------------------- merge_candidates
+// Multi-GPU exchange 1: G devices each contributed K1 ascending distinct (dist,id) keys per query (ids are
+// disjoint across devices).  One thread per query merges the G sorted lists into the K1 globally smallest.
+// in: [G][Q][K1] (the layout an all-gather into one tensor produces); out: [Q][K1], same format as stage1_select.
+__global__ void merge_candidates_kernel(int G, int Q, int K1, const FT *__restrict__ in_d,
+                                        const u32 *__restrict__ in_i, FT *__restrict__ out_d,
+                                        u32 *__restrict__ out_i) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= Q) return;
+  int head[16];  // G <= 16
+  for (int g = 0; g < G; g++) head[g] = 0;
+  for (int t = 0; t < K1; t++) {
+    int best = -1;
+    Key bk = key_max();
+    for (int g = 0; g < G; g++) {
+      if (head[g] >= K1) continue;
+      const size_t at = ((size_t)g * Q + x) * K1 + head[g];
+      const u32 id = in_i[at];
+      if (id == ANN_ID_NONE) continue;  // padding: this list is exhausted
+      const Key k = key_make(in_d[at], id);
+      if (best < 0 || key_less(k, bk)) best = g, bk = k;
+    }
+    if (best < 0) {
+      out_d[(size_t)x * K1 + t] = ft_inf();
+      out_i[(size_t)x * K1 + t] = ANN_ID_NONE;
+    } else {
+      out_d[(size_t)x * K1 + t] = key_dist(bk);
+      out_i[(size_t)x * K1 + t] = key_id(bk);
+      head[best]++;
+    }
+  }
+}
+
 // u32 ids -> the ABI's size_t ids
 __global__ void widen_ids_kernel(size_t count, const u32 *__restrict__ in, size_t *__restrict__ out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -5,11 +5,14 @@ The reference is single-device; this is the multi-GPU design BASELIN
 * rank g owns point rows [g*n/G, (g+1)*n/G) in HBM; bucket tables, graph, projection rows are replicated (ids only);
 * every rank sees the whole query batch (results depend on the batch composition) and derives the
   identical candidate row per query, but gathers rows and computes distances only for ids it owns;
+* exchange 0: each rank hashes one slice of the batch, the codes (4*T bytes per query) are all-gathered;
 * exchange 1: all-gather of each rank's k+1 best distinct (dist,id) candidates per query  (G*(k+1)*8 B/query),
-  merged by a sort to the global k+1 best; the same proof as on one GPU (annhip_stage1_finalize) decides which
-  queries need the exact path; for those (rare) the full distance rows are min-all-reduced;
-* exchange 2: min-all-reduce of the stage-2 distance rows (Lc2 values per query, 65 at k=10), after which every
-  rank runs the reference's network and holds the final result.
+  merged by a device kernel (annhip_merge_candidates) to the global k+1 best; the same proof as on one GPU
+  (annhip_stage1_finalize) decides which queries need the exact path; for those (rare) the full distance rows
+  are min-all-reduced;
+* exchange 2: min-reduce-scatter of the stage-2 distance rows (Lc2 values per query, 65 at k=10): each rank runs
+  the reference's network on its slice of the queries only, and the final ids/distances are all-gathered.
+  (Plain all-gather / min-all-reduce forms are kept as the fallback: fast=False, gloo, uneven batches.)
 
 Every rank ends with the same ids/distances, bit-identical to the single-GPU / reference result.
 
@@ -49,6 +52,13 @@ class HipEngine:
                                      nv.data_ptr())
         return cd, ci, nv
 
+    def merge(self, ndev, all_d, all_i):
+        """all_d/all_i: [ndev, Q, k+1] gathered candidates -> the k+1 globally best per query."""
+        Q, K1 = all_d.shape[1], all_d.shape[2]
+        md, mi = self._e((Q, K1), self.ft, all_d), self._e((Q, K1), torch.int32, all_d)
+        self.lib.annhip_merge_candidates(self.h, ndev, Q, all_d.data_ptr(), all_i.data_ptr(), md.data_ptr(), mi.data_ptr())
+        return md, mi
+
     def finalize(self, cd, ci, nv):
         Q = cd.shape[0]
         top_i, top_d = self._e((Q, self.k), torch.int32, cd), self._e((Q, self.k), self.ft, cd)
@@ -78,12 +88,21 @@ class HipEngine:
 
 
 class ShardedQuery:
-    def __init__(self, ix_or_engine, dist=None, group=None):
+    """fast=True uses the leaner collectives (query-sharded hash codes, all-gather into one tensor + device merge
+    kernel, reduce-scatter + sliced final network + all-gather for stage 2) whenever the batch divides evenly by
+    the world size and the backend offers them; otherwise -- and always with fast=False -- the plain
+    all-gather / all-reduce forms are used.  Both give identical results."""
+
+    def __init__(self, ix_or_engine, dist=None, group=None, fast=True):
         self.eng = ix_or_engine if hasattr(ix_or_engine, "stage1_local") else HipEngine(ix_or_engine)
         self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size(group) > 1) else None
         self.group = group
         self.world = self.dist.get_world_size(group) if self.dist else 1
-        self._stage_via_cpu = bool(self.dist) and self.dist.get_backend(group) == "gloo"
+        self.rank = self.dist.get_rank(group) if self.dist else 0
+        backend = self.dist.get_backend(group) if self.dist else None
+        self._stage_via_cpu = backend == "gloo"
+        self.fast = bool(fast and self.dist and backend != "gloo" and hasattr(self.dist, "all_gather_into_tensor")
+                         and hasattr(self.dist, "reduce_scatter_tensor"))
         self.last_exact = 0
 
     # -- collectives (RCCL on device tensors; gloo stages device tensors through the host) --
@@ -94,6 +113,12 @@ class ShardedQuery:
         outs = [torch.empty_like(src) for _ in range(self.world)]
         self.dist.all_gather(outs, src.contiguous(), group=self.group)
         return [o.to(t.device) for o in outs] if src is not t else outs
+
+    def _gather_stacked(self, t):
+        """[world, *t.shape] through one all-gather into a single tensor."""
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        self.dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+        return out
 
     def _all_min(self, t):
         if not self.dist:
@@ -110,6 +135,8 @@ class ShardedQuery:
         """Global k+1 smallest (dist,id) keys per query from every rank's k+1 (ids are disjoint across ranks)."""
         if not self.dist:
             return cd, ci
+        if self.fast and hasattr(self.eng, "merge") and self.world <= 16:
+            return self.eng.merge(self.world, self._gather_stacked(cd), self._gather_stacked(ci))
         K1 = cd.shape[1]
         if cd.dtype == torch.float32:  # one 64-bit key per candidate, one all-gather, one sort
             key = (cd.view(torch.int32).to(torch.int64) << 32) | _u32(ci)
@@ -128,8 +155,15 @@ class ShardedQuery:
 
     def query(self, y, alias=False):
         """y: [Q,d] (identical on every rank).  Returns (ids int64 [Q,k], squared distances [Q,k])."""
-        e = self.eng
-        codes = e.codes(y)
+        e, G, r = self.eng, self.world, self.rank
+        Q = y.shape[0]
+        even = self.fast and Q % G == 0 and Q >= G
+        qs = Q // G if even else Q
+        # hash codes: every rank needs all of them (Q2 scramble), each computes one slice of the batch
+        if even:
+            codes = self._gather_stacked(e.codes(y[r * qs:(r + 1) * qs].contiguous())).reshape(-1)
+        else:
+            codes = e.codes(y)
         cd, ci, nv = e.stage1_local(y, alias, codes)
         cd, ci = self._merge(cd, ci)
         top_i, top_d, flagged = e.finalize(cd, ci, nv)
@@ -139,8 +173,18 @@ class ShardedQuery:
             self._all_min(dd)
             e.exact_select(1, ids, dd, flagged, top_i, top_d)
         ids2, dd2 = e.stage2_rows(y, alias, top_i, top_d)
-        self._all_min(dd2)
-        out_i = torch.empty_like(top_i)
-        out_d = torch.empty_like(top_d)
-        e.exact_select(2, ids2, dd2, None, out_i, out_d)
+        if even:
+            # each rank min-reduces and sorts only its slice of the queries, then the results are all-gathered
+            mine = torch.empty((qs, dd2.shape[1]), dtype=dd2.dtype, device=dd2.device)
+            self.dist.reduce_scatter_tensor(mine, dd2, op=self.dist.ReduceOp.MIN, group=self.group)
+            loc_i = torch.empty((qs, top_i.shape[1]), dtype=top_i.dtype, device=top_i.device)
+            loc_d = torch.empty((qs, top_d.shape[1]), dtype=top_d.dtype, device=top_d.device)
+            e.exact_select(2, ids2[r * qs:(r + 1) * qs].contiguous(), mine, None, loc_i, loc_d)
+            out_i = self._gather_stacked(loc_i).reshape(Q, -1)
+            out_d = self._gather_stacked(loc_d).reshape(Q, -1)
+        else:
+            self._all_min(dd2)
+            out_i = torch.empty_like(top_i)
+            out_d = torch.empty_like(top_d)
+            e.exact_select(2, ids2, dd2, None, out_i, out_d)
         return _u32(out_i), out_d

@@ -97,6 +97,13 @@ def main():
         del points
         torch.cuda.empty_cache()
         runner = ShardedQuery(ix, dist)
+        try:  # the lean collectives (all_gather_into_tensor / reduce_scatter MIN) first; plain ones if RCCL objects
+            runner.query(batches[0])
+            torch.cuda.synchronize()
+        except Exception as exc:  # noqa: BLE001
+            if rank == 0:
+                print("bench: fast collectives failed (%r); using all_gather/all_reduce" % (exc,), file=sys.stderr)
+            runner = ShardedQuery(ix, dist, fast=False)
         step = lambda y: runner.query(y)
     else:
         out_ids = torch.empty((Q, k), dtype=torch.int64, device=device)

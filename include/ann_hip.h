@@ -66,6 +66,10 @@ void annhip_codes(annhip_index *ix, size_t ycnt, const ftype *y_dev, uint32_t *c
 void annhip_stage1_local(annhip_index *ix, size_t ycnt, const ftype *y_dev, int alias,
                          const uint32_t *codes_dev, ftype *cand_dist_dev, uint32_t *cand_id_dev,
                          uint32_t *nvalid_dev);
+/* 2b. merge: in_*_dev hold every device's stage-1 candidates as [ndev][ycnt][k+1] (what an all-gather into one
+ *     tensor yields); out_*_dev receive the k+1 globally smallest per query, same format. ndev <= 16.        */
+void annhip_merge_candidates(annhip_index *ix, int ndev, size_t ycnt, const ftype *in_dist_dev,
+                             const uint32_t *in_id_dev, ftype *out_dist_dev, uint32_t *out_id_dev);
 /* 3. after the caller merged all devices' candidates into the k+1 globally best (same format):
  *    writes top_id u32[ycnt][k]/top_dist and the list of queries that need the exact path.
  *    Returns their count (synchronises). flagged_dev must hold ycnt entries; the list is ascending, so it is

@@ -31,6 +31,27 @@ class ThreadDist:
     def get_backend(self, group=None):
         return "threads"
 
+    def get_rank(self, group=None):
+        return self.tl.rank
+
+    def all_gather_into_tensor(self, out, t, group=None):
+        self.slots[self.tl.rank] = t
+        self.bar.wait()
+        out.copy_(torch.stack([s_ for s_ in self.slots]).reshape(out.shape))
+        torch.cuda.synchronize()
+        self.bar.wait()
+
+    def reduce_scatter_tensor(self, out, t, op=None, group=None):
+        self.slots[self.tl.rank] = t
+        self.bar.wait()
+        res = self.slots[0]
+        for s_ in self.slots[1:]:
+            res = torch.minimum(res, s_)
+        n = out.shape[0]
+        out.copy_(res[self.tl.rank * n:(self.tl.rank + 1) * n])
+        torch.cuda.synchronize()
+        self.bar.wait()
+
     def all_gather(self, outs, t, group=None):
         self.slots[self.tl.rank] = t
         self.bar.wait()
@@ -51,7 +72,7 @@ class ThreadDist:
         self.bar.wait()
 
 
-def _run_sharded(prec, save_arrays, pts, y, world, alias=False):
+def _run_sharded(prec, save_arrays, pts, y, world, alias=False, fast=True):
     save = A.Save.from_dict(prec, save_arrays)
     td = ThreadDist(world)
     results, errors = [None] * world, []
@@ -62,7 +83,8 @@ def _run_sharded(prec, save_arrays, pts, y, world, alias=False):
             td.tl.rank = rank
             lo, hi = (len(pts) * rank) // world, (len(pts) * (rank + 1)) // world
             ix = A.Index.from_save(save, torch.from_numpy(np.ascontiguousarray(pts[lo:hi])).cuda(), lo, hi)
-            sq = ShardedQuery(ix, td)
+            sq = ShardedQuery(ix, td, fast=fast)
+            assert sq.fast == fast
             ids, dd = sq.query(yt, alias=alias)
             torch.cuda.synchronize()
             results[rank] = (ids.cpu().numpy().astype(np.uint64), dd.cpu().numpy(), sq.last_exact)
@@ -77,11 +99,14 @@ def _run_sharded(prec, save_arrays, pts, y, world, alias=False):
     return results
 
 
+@pytest.mark.parametrize("fast", [True, False])
 @pytest.mark.parametrize("name,world", [("pow2_d128_f32", 2), ("pow2_d128_f64", 3), ("defaults_d80_f32", 2),
-                                        ("pow2_d32_f32", 4), ("k17_d100_f64", 2), ("few_candidates_f32", 2)])
-def test_sharded_on_one_gpu_matches_golden(name, world):
+                                        ("pow2_d32_f32", 4), ("k17_d100_f64", 2), ("few_candidates_f32", 2),
+                                        ("pow2_d64_f32", 8)])
+def test_sharded_on_one_gpu_matches_golden(name, world, fast):
+    # Q divisible by the world size (fast collectives: sharded codes, device merge, reduce-scatter) and not
     g = load_golden(name)
-    for ids, dd, _ in _run_sharded(g["prec"], g["save"], g["points"], g["y"], world):
+    for ids, dd, _ in _run_sharded(g["prec"], g["save"], g["points"], g["y"], world, fast=fast):
         assert np.array_equal(ids, g["query_ids"]) and bits_equal(dd, g["query_dists"])
 
 
@@ -113,7 +138,7 @@ def test_ties_take_the_exact_path_and_still_match(prec):
         assert nex > len(y) // 2, "duplicated points must trip the tie test for most queries (got %d)" % nex
         assert np.array_equal(r_ids.cpu().numpy().astype(np.uint64), want[0])
         ix.close()
-        for s_ids, s_d, s_ex in _run_sharded(prec, o_save, pts, y, 2):
+        for s_ids, s_d, s_ex in _run_sharded(prec, o_save, pts, y, 2) + _run_sharded(prec, o_save, pts, y, 3, fast=False):
             assert np.array_equal(s_ids, want[0]) and bits_equal(s_d, want[1]) and s_ex > 0
     finally:
         A._lib.load(prec).annhip_cache_clear()
