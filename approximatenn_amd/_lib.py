@@ -57,6 +57,10 @@ def load(prec="f32"):
     lib.annhip_index_set_stream.argtypes = [vp, vp]
     lib.annhip_index_export.argtypes = [vp, C.POINTER(SaveT)]
     lib.annhip_index_reshard.argtypes = [vp, vp, sz, sz]
+    lib.annhip_save_write.restype = C.c_int
+    lib.annhip_save_write.argtypes = [C.POINTER(SaveT), C.c_char_p]
+    lib.annhip_save_read.restype = C.c_int
+    lib.annhip_save_read.argtypes = [C.c_char_p, C.POINTER(SaveT)]
     lib.annhip_precomp_index.restype = vp
     lib.annhip_precomp_index.argtypes = [sz, sz, sz, vp, C.c_int, C.c_int, sz, sz, sz, sz, vp]
     lib.annhip_query.restype = C.c_long
@@ -87,7 +91,7 @@ def load(prec="f32"):
 # every symbol include/*.h declares for the backend library (checked by tests/test_abi.py)
 EXPORTED = ["gpu_init", "gpu_cleanup", "register_cleanup", "query_gpu", "precomp_gpu", "annhip_precision",
             "annhip_index_create", "annhip_index_destroy", "annhip_index_info", "annhip_index_set_stream",
-            "annhip_index_export", "annhip_index_reshard", "annhip_precomp_index", "annhip_query", "annhip_codes", "annhip_stage1_local",
+            "annhip_index_export", "annhip_index_reshard", "annhip_save_write", "annhip_save_read", "annhip_precomp_index", "annhip_query", "annhip_codes", "annhip_stage1_local",
             "annhip_merge_candidates", "annhip_stage1_finalize", "annhip_stage1_rows", "annhip_stage2_rows", "annhip_exact_select",
             "annhip_widen_ids", "annhip_profile", "annhip_stats"]
 DISPATCH_EXPORTED = ["precomp", "query", "free_save"]

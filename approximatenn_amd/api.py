@@ -78,6 +78,20 @@ class Save:
                     row_means=np.ctypeslib.as_array(C.cast(c.row_means, C.POINTER(cft)), shape=(d,)).copy(),
                     bases=np.ctypeslib.as_array(C.cast(c.bases, C.POINTER(cft)), shape=(T, ds, d)).copy())
 
+    def write(self, path):
+        """annhip_save_write: one checksummed index file (include/ann_hip.h)."""
+        if _lib.load(self.prec).annhip_save_write(C.byref(self.c), str(path).encode()) != 0:
+            raise OSError("could not write index file %s" % path)
+
+    @classmethod
+    def read(cls, prec, path):
+        """annhip_save_read: load an index file written by the same-precision library."""
+        s = cls(prec)
+        if _lib.load(prec).annhip_save_read(str(path).encode(), C.byref(s.c)) != 0:
+            raise OSError("could not read index file %s" % path)
+        s._malloced = True
+        return s
+
     def free(self):
         """free_save (/root/reference/ann.c:25-34) for library-filled structs."""
         if self._malloced:

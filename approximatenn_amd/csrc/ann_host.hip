@@ -167,6 +167,7 @@ struct annhip_index {
   hipStream_t stream = 0;
   // workspace of annhip_query
   DevBuf codes, cand_d, cand_i, nvt, nvo, top_i, top_d, flist, xids, xd, r2i, r2d, out_i, out_d;
+  DevBuf io_y, io_ids, io_dist;  // query_gpu's staging of host inputs/outputs, reused between calls
   u32 *d_fcount = NULL;
   unsigned long long *d_rows = NULL;  // [0] stage-1 gathered rows, [2] exact-path queries, [8..8+512) rows kernels (64 padded shards)
   // measurement
@@ -300,7 +301,8 @@ extern "C" void annhip_index_destroy(annhip_index *ix) {
   if (ix->d_fcount) HIPCHECK(hipFree(ix->d_fcount));
   if (ix->d_rows) HIPCHECK(hipFree(ix->d_rows));
   DevBuf *bufs[] = {&ix->codes, &ix->cand_d, &ix->cand_i, &ix->nvt, &ix->nvo, &ix->top_i, &ix->top_d,
-                    &ix->flist, &ix->xids,  &ix->xd,     &ix->r2i, &ix->r2d, &ix->out_i, &ix->out_d};
+                    &ix->flist, &ix->xids,  &ix->xd,     &ix->r2i, &ix->r2d, &ix->out_i, &ix->out_d,
+                    &ix->io_y,  &ix->io_ids, &ix->io_dist};
   for (DevBuf *b : bufs) b->release();
   for (auto &e : ix->ev_used) (void)hipEventDestroy(e.a), (void)hipEventDestroy(e.b);
   for (auto &e : ix->ev_free) (void)hipEventDestroy(e.a), (void)hipEventDestroy(e.b);
@@ -1032,17 +1034,14 @@ extern "C" size_t *query_gpu(const save_t *save, const ftype *points, size_t ycn
   size_t *result = (size_t *)malloc(sizeof(size_t) * (ycnt * k ? ycnt * k : 1));
   if (dists_o) *dists_o = (ftype *)malloc(sizeof(ftype) * (ycnt * k ? ycnt * k : 1));
   if (!ycnt) return result;
-  FT *y_dev = dev_alloc<FT>(ycnt * d);
-  size_t *ids_dev = dev_alloc<size_t>(ycnt * k);
-  FT *dist_dev = dev_alloc<FT>(ycnt * k);
+  FT *y_dev = (FT *)ix->io_y.need(sizeof(FT) * ycnt * d);
+  size_t *ids_dev = (size_t *)ix->io_ids.need(sizeof(size_t) * ycnt * k);
+  FT *dist_dev = (FT *)ix->io_dist.need(sizeof(FT) * ycnt * k);
   HIPCHECK(hipMemcpy(y_dev, y, sizeof(FT) * ycnt * d, hipMemcpyHostToDevice));
   annhip_query(ix, ycnt, y_dev, y == points, 0, ids_dev, dist_dev);
   HIPCHECK(hipStreamSynchronize(ix->stream));
   HIPCHECK(hipMemcpy(result, ids_dev, sizeof(size_t) * ycnt * k, hipMemcpyDeviceToHost));
   if (dists_o) HIPCHECK(hipMemcpy(*dists_o, dist_dev, sizeof(FT) * ycnt * k, hipMemcpyDeviceToHost));
-  HIPCHECK(hipFree(y_dev));
-  HIPCHECK(hipFree(ids_dev));
-  HIPCHECK(hipFree(dist_dev));
   return result;
 }
 

@@ -39,6 +39,13 @@ void annhip_index_reshard(annhip_index *ix, const ftype *shard_points_dev, size_
 /* Download the index into a save_t whose fields are malloc'd (free_save() releases it). */
 void annhip_index_export(const annhip_index *ix, save_t *save);
 
+/* ---- index files (the reference's save_t is memory-only) ------------------------------------ */
+/* Write / read a save_t (format: approximatenn_amd/csrc/ann_saveio.cpp; checksummed; ids stored as 32 bit when
+ * they fit).  Host-only.  Return 0 on success; on failure print to stderr and return -1 (read leaves *save zeroed).
+ * A file is tied to the precision of the library that wrote it.  Read fills malloc'd fields (free_save()).        */
+int annhip_save_write(const save_t *save, const char *path);
+int annhip_save_read(const char *path, save_t *save);
+
 /* ---- precomp on the device (alg.c:342-434) ----------------------------------------------------- */
 /* Builds the index from ALL n rows on this device and keeps it resident.  Consumes libc random() in the
  * reference's order.  graph_dists_dev (device, ftype[n*k]) may be NULL. */
