@@ -48,6 +48,28 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Value of lane (i + N) of the same 16-lane row, N in 1..15, by DPP (row_shl:N) -- no LDS crossbar traffic.
+// Lanes whose source falls outside the row read 0; callers only use lanes whose source is inside.
+template <int N>
+__device__ __forceinline__ float lane_up(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + N, 0xF, 0xF, true));
+}
+template <int N>
+__device__ __forceinline__ double lane_up(double v) {
+  const u64 b = __builtin_bit_cast(u64, v);
+  const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)b, 0x100 + N, 0xF, 0xF, true);
+  const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(b >> 32), 0x100 + N, 0xF, 0xF, true);
+  return __builtin_bit_cast(double, ((u64)hi << 32) | lo);
+}
+// partner value for the tree level that pairs lane position p with p + M (M a power of two)
+template <int M>
+__device__ __forceinline__ FT tree_partner(FT v) {
+  if constexpr (M <= 8)
+    return lane_up<M>(v);  // groups of LPR <= 16 lanes are aligned inside a 16-lane DPP row
+  else
+    return __shfl_xor(v, M);
+}
+
 // ------------------------------------------------------------------ candidate keys
 // A candidate is (squared distance, point id).  Distances are >= +0, so their bit patterns order like
 // the values; (dist_bits, id) ordered lexicographically is the total order used by the selection path.
@@ -136,7 +158,8 @@ enum { ROW_SQDIFF = 0, ROW_PRODUCT = 1 };
 // One row against the lane's slice `a` of the left operand.  MODE ROW_SQDIFF: sum (a-b)^2 (compute.cl:
 // 147-149); ROW_PRODUCT: sum a*b (compute.cl:268-275), with the reference's "+ 0" kept in every tree
 // node because it turns -0 into +0 and the hash reads the raw sign bit (compute.cl:165-166,229).
-// The result is valid in lane position 0 of each LPR-lane group.
+// The result is valid in lane position 0 of each LPR-lane group ONLY (the cross-lane levels pull the partner's
+// value downwards with DPP row shifts; the other lanes end up with partial sums nobody reads).
 template <int D, int MODE>
 __device__ __forceinline__ FT row_reduce(const VT (&a)[RowLay<D>::C], const VT (&b)[RowLay<D>::C]) {
   typedef RowLay<D> L;
@@ -163,13 +186,15 @@ __device__ __forceinline__ FT row_reduce(const VT (&a)[RowLay<D>::C], const VT (
 #pragma unroll
       for (int j = 0; j < ANN_VEC; j++)
         e[c][j] = (MODE == ROW_PRODUCT) ? e[c][j] + (e[c + h][j] + zero) : e[c][j] + e[c + h][j];
-#pragma unroll
-  for (int m = L::LPR / 2; m >= 1; m >>= 1)
-#pragma unroll
-    for (int j = 0; j < ANN_VEC; j++) {
-      FT o = __shfl_xor(e[0][j], m);
-      e[0][j] = (MODE == ROW_PRODUCT) ? e[0][j] + (o + zero) : e[0][j] + o;
-    }
+#define ANN_TREE_LEVEL(M)                                                                  \
+  if constexpr (L::LPR / 2 >= (M)) {                                                       \
+    _Pragma("unroll") for (int j = 0; j < ANN_VEC; j++) {                                   \
+      FT o = tree_partner<(M)>(e[0][j]);                                                   \
+      e[0][j] = (MODE == ROW_PRODUCT) ? e[0][j] + (o + zero) : e[0][j] + o;                 \
+    }                                                                                      \
+  }
+  ANN_TREE_LEVEL(32) ANN_TREE_LEVEL(16) ANN_TREE_LEVEL(8) ANN_TREE_LEVEL(4) ANN_TREE_LEVEL(2) ANN_TREE_LEVEL(1)
+#undef ANN_TREE_LEVEL
 #pragma unroll
   for (int h = ANN_VEC / 2; h >= 1; h >>= 1)
 #pragma unroll

@@ -383,8 +383,11 @@ static void allow_lds(K kernel, size_t bytes) {
     HIPCHECK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
 }
 
-static void launch_codes(const QParams &P, size_t Q, const FT *y, u32 *codes, hipStream_t s) {
+// Qhash <= Q: only the first Qhash queries are hashed.  Stage 1 reads code[i*Q + x] for the tries i that own a
+// slot below Lc1, i.e. flat indices below tries_used*Q, i.e. queries below ceil(tries_used*Q/T).
+static void launch_codes(const QParams &P, size_t Qhash, const FT *y, u32 *codes, hipStream_t s) {
   const int wpb = 4;
+  const size_t Q = Qhash;
   const size_t items = Q * (size_t)P.T;
   if (!items) return;
   if (d_is_fast(P.d)) {  // workgroup = (try, run of queries); the try's projection rows live in LDS
@@ -587,7 +590,12 @@ extern "C" long annhip_query(annhip_index *ix, size_t Q, const ftype *y_dev, int
   if (getenv("ANN_HIP_EXACT")) mode = 1;
   if ((u32)k > P.P1) mode = 1;
   u32 *codes = (u32 *)ix->codes.need(sizeof(u32) * Q * P.T);
-  launch_codes(P, Q, y, codes, s);
+  {
+    int tries_used = 0;
+    while (tries_used < ix->T && ix->h_tries[tries_used].off < ix->Lc1) tries_used++;
+    const size_t qhash = std::min(Q, ((size_t)tries_used * Q + ix->T - 1) / ix->T);
+    launch_codes(P, qhash, y, codes, s);
+  }
   u32 *top_i = (u32 *)ix->top_i.need(sizeof(u32) * Q * k);
   FT *top_d = (FT *)ix->top_d.need(sizeof(FT) * Q * k);
   FT *cand_d = NULL;
