@@ -444,8 +444,10 @@ __global__ void sum_u32_kernel(size_t count, const u32 *__restrict__ v, unsigned
 }
 
 static void launch_stage1(annhip_index *ix, const QParams &P, size_t Q, const FT *y, int alias,
-                          const u32 *codes, FT *cand_d, u32 *cand_i, u32 *nvt, u32 *nvo, hipStream_t s) {
+                          const u32 *codes, FT *cand_d, u32 *cand_i, u32 *nvt, u32 *nvo, hipStream_t s,
+                          bool stream_rows = true) {
   if (!Q) return;
+  if (getenv("ANN_HIP_CACHED_ROWS")) stream_rows = false;  // A/B switch: plain (cached) row loads
   const int K1 = P.k + 1, W = stage1_waves(P.P1), cap = stage1_cap(W, K1);
   const size_t smem = stage1_lds_bytes(P, W, K1, cap);
   EventPair ev;
@@ -460,11 +462,17 @@ static void launch_stage1(annhip_index *ix, const QParams &P, size_t Q, const FT
     }
     HIPCHECK(hipEventRecord(ev.a, s));
   }
-#define CALL(DD)                                                                                       \
-  do {                                                                                                 \
-    allow_lds(stage1_select_kernel<DD>, smem);                                                         \
-    hipLaunchKernelGGL(stage1_select_kernel<DD>, dim3((unsigned)Q), dim3(64 * W), smem, s, P, (int)Q, y, \
-                       alias, codes, K1, cap, cand_d, cand_i, nvt, nvo);                               \
+#define CALL(DD)                                                                                            \
+  do {                                                                                                      \
+    if (stream_rows) {                                                                                      \
+      allow_lds(stage1_select_kernel<DD, true>, smem);                                                      \
+      hipLaunchKernelGGL((stage1_select_kernel<DD, true>), dim3((unsigned)Q), dim3(64 * W), smem, s, P, (int)Q, y, \
+                         alias, codes, K1, cap, cand_d, cand_i, nvt, nvo);                                  \
+    } else {                                                                                                \
+      allow_lds(stage1_select_kernel<DD, false>, smem);                                                     \
+      hipLaunchKernelGGL((stage1_select_kernel<DD, false>), dim3((unsigned)Q), dim3(64 * W), smem, s, P, (int)Q, y, \
+                         alias, codes, K1, cap, cand_d, cand_i, nvt, nvo);                                  \
+    }                                                                                                       \
   } while (0)
   ANN_DISPATCH_D(P.d, CALL);
 #undef CALL
@@ -921,7 +929,7 @@ extern "C" annhip_index *annhip_precomp_index(size_t n, size_t k, size_t d, cons
       ci = (u32 *)cand_i.need(sizeof(u32) * n * (k + 1));
       nv = (u32 *)nvt.need(sizeof(u32) * n);
       u32 *no = (u32 *)nvo.need(sizeof(u32) * n);
-      launch_stage1(NULL, P, n, pts, 1, codes[t], cd, ci, nv, no, s);
+      launch_stage1(NULL, P, n, pts, 1, codes[t], cd, ci, nv, no, s, getenv("ANN_HIP_CACHED_ROWS") == NULL);
     }
     finalize_and_fallback(NULL, P, n, pts, 1, codes[t], mode, cd, ci, nv, merged_i, merged_d, (int)W, (int)(t * k),
                           flist, xids, xd, ix->d_fcount, NULL, NULL, false, s);

@@ -39,6 +39,21 @@ struct QParams {
 
 #define ANN_S1_CHUNK 1024  // slots whose valid ids one wave stages in LDS at a time
 
+// One 16-byte chunk of a gathered point row.  NT: query batches read each candidate row once and never again,
+// so the load is marked non-temporal and does not displace the re-used bucket tables / graph in L2 and the
+// Infinity Cache (measured at cfg3: stage-1 kernel 1.244 -> 1.166 ms).  precomp keeps cached loads: there the
+// same rows are candidates of every bucket-mate.
+template <bool NT>
+__device__ __forceinline__ VT load_row_chunk(const VT *p) {
+  if constexpr (NT) {
+    typedef FT native_vec __attribute__((ext_vector_type(ANN_VEC)));
+    native_vec v = __builtin_nontemporal_load(reinterpret_cast<const native_vec *>(p));
+    return __builtin_bit_cast(VT, v);
+  } else {
+    return *p;
+  }
+}
+
 // ------------------------------------------------------------------------------------------ codes
 // code[q*T+t] (the reference's WRITE layout; stage 1 reads it back as [i*Q+x]).
 //
@@ -129,7 +144,7 @@ __device__ __forceinline__ u32 slot_id(const TryInfo *tries, const u32 *qcode, u
 //      that buffer with wave_select_smallest whenever it fills.
 // The waves' survivors are merged by wave 0.  Output per query: K1 = k+1 ascending distinct keys (padded
 // with (+inf, ANN_ID_NONE)), the number of valid slots (for the +inf test of finalize1) and of gathered rows.
-template <int D>
+template <int D, bool NT>
 __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, const FT *__restrict__ y,
                                                             int alias, const u32 *__restrict__ codes,
                                                             int K1, int cap, FT *__restrict__ cand_dist,
@@ -207,7 +222,7 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
         idn = list[g < cnt ? g : 0];
         const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(idn - P.lo) * D) + p;
 #pragma unroll
-        for (int c = 0; c < L::C; c++) bn[c] = rp[c * L::LPR];
+        for (int c = 0; c < L::C; c++) bn[c] = load_row_chunk<NT>(rp + c * L::LPR);
       }
       for (int base = 0; base < cnt; base += L::RPW) {
         VT b[L::C];
@@ -220,7 +235,7 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
           idn = list[nb + g < cnt ? nb + g : nb];
           const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(idn - P.lo) * D) + p;
 #pragma unroll
-          for (int c = 0; c < L::C; c++) bn[c] = rp[c * L::LPR];
+          for (int c = 0; c < L::C; c++) bn[c] = load_row_chunk<NT>(rp + c * L::LPR);
         }
         const FT dist = row_reduce<D, ROW_SQDIFF>(a, b);
         const Key key = key_make(dist, id);
@@ -429,7 +444,7 @@ __global__ __launch_bounds__(256) void row_dists_kernel(QParams P, int Q, const 
         const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(id - P.lo) * D) + p;
         VT b[L::C];
 #pragma unroll
-        for (int c = 0; c < L::C; c++) b[c] = rp[c * L::LPR];
+        for (int c = 0; c < L::C; c++) b[c] = load_row_chunk<true>(rp + c * L::LPR);
         const FT dist = row_reduce<D, ROW_SQDIFF>(a, b);
         if (act && p == 0) dist_row[lslot[r]] = dist;
       }
