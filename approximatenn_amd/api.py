@@ -240,6 +240,11 @@ class Index:
         return dict(s1_launches=out[0], s1_ms=out[1], s1_rows=out[2], other_rows=out[3], exact_queries=out[4],
                     queries=out[5])
 
+    def stage_ms(self):
+        out = (C.c_double * 6)()
+        self.lib.annhip_stage_ms(self.h, C.byref(out))
+        return dict(zip(("codes", "stage1", "finalize_fallback", "stage2_rows", "stage2_network", "widen"), [float(v) for v in out]))
+
     def close(self):
         if self.h:
             self.lib.annhip_index_destroy(self.h)

@@ -251,7 +251,10 @@ __host__ __device__ inline size_t ann_need_len(size_t L, size_t k) {
 
 // do_sort (alg.c:137-144) on one row held in LDS or global memory, executed by one workgroup.
 // L is the reference's row length (it clips pairs with ib >= L); only indices < ann_need_len are touched.
-template <typename KP, typename IP>
+// Pair pr is owned by thread pr % blockDim.x.  For sub-steps with stride 2^ss <= 32 the 64 pairs of one wave
+// only touch that wave's own 128 entries (in every pass of blockDim.x pairs), so consecutive such sub-steps
+// need a wave-level fence, not a workgroup barrier: 33 instead of 78 barriers per sort at 4096 entries.
+template <bool IN_LDS, typename KP, typename IP>
 __device__ inline void block_sort_net(size_t L, KP key, IP ids) {
   const int lk = ann_lg(L);
   const u32 npairs = 8u << (lk > 4 ? lk - 4 : 0);
@@ -271,19 +274,22 @@ __device__ inline void block_sort_net(size_t L, KP key, IP ids) {
           }
         }
       }
-      __syncthreads();
+      if (IN_LDS && ss > 0 && ss <= 5)
+        wave_lds_sync();  // the next sub-step (stride 2^(ss-1)) stays inside this wave's entries
+      else
+        __syncthreads();
     }
 }
 
 // sort_and_uniq (alg.c:224-230): network, kill the first of each adjacent equal-id pair, network.
 // `len` = number of stored entries (>= ann_need_len(L,k)).
-template <typename KP, typename IP>
+template <bool IN_LDS, typename KP, typename IP>
 __device__ inline void block_topk_stage(size_t L, size_t len, KP key, IP ids) {
-  block_sort_net(L, key, ids);
+  block_sort_net<IN_LDS>(L, key, ids);
   const FT inf = ft_inf();
   // every y reads ids only and writes its own key: no hazard inside the pass
   for (size_t y = threadIdx.x; y + 1 < len; y += blockDim.x)
     if (ids[y] == ids[y + 1]) key[y] = key[y] + inf;
   __syncthreads();
-  block_sort_net(L, key, ids);
+  block_sort_net<IN_LDS>(L, key, ids);
 }

@@ -173,6 +173,9 @@ struct annhip_index {
   // measurement
   bool profile = false;
   std::vector<EventPair> ev_used, ev_free;
+  std::vector<hipEvent_t> seg_free;
+  std::vector<std::vector<hipEvent_t>> seg_used;  // per call: events at the stage boundaries
+  double seg_ms[6] = {0, 0, 0, 0, 0, 0};          // codes, stage1, finalize+fallback, stage-2 rows, stage-2 network, widen
   double s1_ms = 0;
   double s1_launches = 0, queries = 0;
 };
@@ -306,6 +309,9 @@ extern "C" void annhip_index_destroy(annhip_index *ix) {
   for (DevBuf *b : bufs) b->release();
   for (auto &e : ix->ev_used) (void)hipEventDestroy(e.a), (void)hipEventDestroy(e.b);
   for (auto &e : ix->ev_free) (void)hipEventDestroy(e.a), (void)hipEventDestroy(e.b);
+  for (hipEvent_t e : ix->seg_free) (void)hipEventDestroy(e);
+  for (auto &m : ix->seg_used)
+    for (hipEvent_t e : m) (void)hipEventDestroy(e);
   delete ix;
 }
 
@@ -434,6 +440,9 @@ static size_t stage1_lds_bytes(const QParams &P, int W, int K1, int cap) {
   return b;
 }
 
+// hipMemsetAsync on 4 bytes cost ~100 us of stream time between kernels on ROCm 7.2; a one-thread kernel does not
+__global__ void zero_u32_kernel(u32 *p) { *p = 0; }
+
 __global__ void sum_u32_kernel(size_t count, const u32 *__restrict__ v, unsigned long long *out) {
   unsigned long long acc = 0;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (size_t)gridDim.x * blockDim.x)
@@ -498,15 +507,21 @@ static void launch_rows(const QParams &P, size_t Q, const FT *y, int alias, cons
                         u32 xbase, size_t nq, u32 len, const u32 *top_i, const FT *top_d, u32 *ids, FT *dist,
                         unsigned long long *rows_done, hipStream_t s, const u32 *live_rows = NULL) {
   if (!nq) return;
-  const u32 chunk = len < ANN_RD_CHUNK ? ((len + 63u) & ~63u) : ANN_RD_CHUNK;  // LDS lists sized to the row
+  // long rows (exact path, a handful of rows) are split over up to 8 workgroups; short rows get one
+  const unsigned split = len >= 1024 ? 8 : 1;
+  u32 chunk = len < ANN_RD_CHUNK ? ((len + 63u) & ~63u) : ANN_RD_CHUNK;  // LDS lists sized to the row
+  if (split > 1) chunk = std::max<u32>(256, (((len + split - 1) / split) + 63u) & ~63u);
+  if (chunk > ANN_RD_CHUNK) chunk = ANN_RD_CHUNK;
   const size_t smem = rows_lds_bytes(P, chunk);
   // short rows (stage 2 at small k): fewer waves per row, more rows resident per CU
   const unsigned block = len <= 128 ? 128 : 256;
+  const unsigned grid = live_rows ? (unsigned)std::min<size_t>(nq, 512) : (unsigned)nq;
 #define CALL(DD)                                                                                         \
   do {                                                                                                   \
     allow_lds(row_dists_kernel<DD, MODE>, smem);                                                         \
-    hipLaunchKernelGGL((row_dists_kernel<DD, MODE>), dim3((unsigned)nq), dim3(block), smem, s, P, (int)Q, y, \
-                       alias, codes, qidx, xbase, len, top_i, top_d, ids, dist, rows_done, live_rows, chunk); \
+    hipLaunchKernelGGL((row_dists_kernel<DD, MODE>), dim3(grid, split), dim3(block), smem, s, P, (int)Q, y, \
+                       alias, codes, qidx, xbase, len, top_i, top_d, ids, dist, rows_done, live_rows,        \
+                       (u32)nq, chunk);                                                                      \
   } while (0)
   ANN_DISPATCH_D(P.d, CALL);
 #undef CALL
@@ -520,16 +535,17 @@ static void launch_exact_select(u32 L, u32 len, u32 in_stride, int k, size_t nq,
   if (!nq) return;
   const int lk = ann_lg(L);
   unsigned npairs = 8u << (lk > 4 ? lk - 4 : 0);
-  unsigned block = npairs >= 256 ? 256 : ((npairs + 63) / 64) * 64;
+  unsigned block = npairs >= 1024 ? 1024 : ((npairs + 63) / 64) * 64;  // one pair per thread up to the 1024 limit
   if (block < 64) block = 64;
   const size_t smem = (size_t)len * (sizeof(FT) + sizeof(u32));
+  const unsigned grid = live_rows ? (unsigned)std::min<size_t>(nq, 512) : (unsigned)nq;
   if (smem <= 150 * 1024) {  // the whole row in LDS (one CU has 160 KB); longer rows sort in place in HBM
     allow_lds(exact_select_kernel<true>, smem);
-    hipLaunchKernelGGL(exact_select_kernel<true>, dim3((unsigned)nq), dim3(block), smem, s, L, len, in_stride, k,
-                       ids, dist, qidx, xbase, out_i, out_d, ostride, ooff, live_rows);
+    hipLaunchKernelGGL(exact_select_kernel<true>, dim3(grid), dim3(block), smem, s, L, len, in_stride, k,
+                       ids, dist, qidx, xbase, out_i, out_d, ostride, ooff, live_rows, (u32)nq);
   } else
-    hipLaunchKernelGGL(exact_select_kernel<false>, dim3((unsigned)nq), dim3(block), 0, s, L, len, in_stride, k,
-                       ids, dist, qidx, xbase, out_i, out_d, ostride, ooff, live_rows);
+    hipLaunchKernelGGL(exact_select_kernel<false>, dim3(grid), dim3(block), 0, s, L, len, in_stride, k,
+                       ids, dist, qidx, xbase, out_i, out_d, ostride, ooff, live_rows, (u32)nq);
   HIPCHECK(hipGetLastError());
 }
 
@@ -551,11 +567,12 @@ static long finalize_and_fallback(annhip_index *ix, const QParams &P, size_t Q, 
   size_t chunk = ((size_t)1 << 30) / (row_bytes ? row_bytes : 1);
   if (chunk < 1) chunk = 1;
   if (mode == 0) {
-    HIPCHECK(hipMemsetAsync(d_fcount, 0, sizeof(u32), s));
+    zero_u32_kernel<<<1, 1, 0, s>>>(d_fcount);
     hipLaunchKernelGGL(finalize1_kernel, dim3(grid_for(Q, 256, 1u << 30)), dim3(256), 0, s, (int)Q, P.k, K1, P.L1,
                        P.P1, cand_d, cand_i, nvt, top_i, top_d, ostride, ooff, fl, d_fcount, exact_total);
     HIPCHECK(hipGetLastError());
     if (device_driven && Q <= chunk) {
+      if (getenv("ANN_HIP_DEBUG_SKIP_FALLBACK")) return -1;  // timing experiments only (wrong results on ties)
       u32 *ids = (u32 *)xids.need(sizeof(u32) * Q * P.Lc1);
       FT *dist = (FT *)xd.need(sizeof(FT) * Q * P.Lc1);
       launch_rows<MODE_TABLE>(P, Q, y, alias, codes, fl, 0, Q, P.Lc1, NULL, NULL, ids, dist, rows_done, s, d_fcount);
@@ -586,6 +603,19 @@ static long finalize_and_fallback(annhip_index *ix, const QParams &P, size_t Q, 
   return (long)nflag;
 }
 
+static void seg_mark(annhip_index *ix, std::vector<hipEvent_t> *marks, hipStream_t s) {
+  if (!marks) return;
+  hipEvent_t e;
+  if (ix->seg_free.empty()) {
+    HIPCHECK(hipEventCreate(&e));
+  } else {
+    e = ix->seg_free.back();
+    ix->seg_free.pop_back();
+  }
+  HIPCHECK(hipEventRecord(e, s));
+  marks->push_back(e);
+}
+
 // ----------------------------------------------------------------------------- query
 extern "C" long annhip_query(annhip_index *ix, size_t Q, const ftype *y_dev, int alias, int mode,
                              size_t *ids_dev, ftype *dists_dev) {
@@ -597,6 +627,8 @@ extern "C" long annhip_query(annhip_index *ix, size_t Q, const ftype *y_dev, int
   const int k = P.k, K1 = k + 1;
   if (getenv("ANN_HIP_EXACT")) mode = 1;
   if ((u32)k > P.P1) mode = 1;
+  std::vector<hipEvent_t> marks_store, *marks = ix->profile ? &marks_store : NULL;
+  seg_mark(ix, marks, s);
   u32 *codes = (u32 *)ix->codes.need(sizeof(u32) * Q * P.T);
   {
     int tries_used = 0;
@@ -604,6 +636,7 @@ extern "C" long annhip_query(annhip_index *ix, size_t Q, const ftype *y_dev, int
     const size_t qhash = std::min(Q, ((size_t)tries_used * Q + ix->T - 1) / ix->T);
     launch_codes(P, qhash, y, codes, s);
   }
+  seg_mark(ix, marks, s);
   u32 *top_i = (u32 *)ix->top_i.need(sizeof(u32) * Q * k);
   FT *top_d = (FT *)ix->top_d.need(sizeof(FT) * Q * k);
   FT *cand_d = NULL;
@@ -615,9 +648,11 @@ extern "C" long annhip_query(annhip_index *ix, size_t Q, const ftype *y_dev, int
     u32 *nvo = (u32 *)ix->nvo.need(sizeof(u32) * Q);
     launch_stage1(ix, P, Q, y, alias, codes, cand_d, cand_i, nvt, nvo, s);
   }
+  seg_mark(ix, marks, s);
   unsigned long long *rows_ctr = ix->profile ? ix->d_rows + 8 : NULL;
   long nflag = finalize_and_fallback(ix, P, Q, y, alias, codes, mode, cand_d, cand_i, nvt, top_i, top_d, k, 0,
                                      ix->flist, ix->xids, ix->xd, ix->d_fcount, rows_ctr, ix->d_rows + 2, true, s);
+  seg_mark(ix, marks, s);
   // stage 2 (det_results second half, alg.c:314-327)
   u32 *out_i = (u32 *)ix->out_i.need(sizeof(u32) * Q * k);
   FT *out_d = dists_dev ? reinterpret_cast<FT *>(dists_dev) : (FT *)ix->out_d.need(sizeof(FT) * Q * k);
@@ -629,10 +664,14 @@ extern "C" long annhip_query(annhip_index *ix, size_t Q, const ftype *y_dev, int
     u32 *r2i = (u32 *)ix->r2i.need(sizeof(u32) * nq * P.Lc2);
     FT *r2d = (FT *)ix->r2d.need(sizeof(FT) * nq * P.Lc2);
     launch_rows<MODE_GRAPH>(P, Q, y, alias, NULL, NULL, (u32)q0, nq, P.Lc2, top_i, top_d, r2i, r2d, rows_ctr, s);
+    if (q0 + chunk >= Q) seg_mark(ix, marks, s);
     launch_exact_select(P.L2, P.Lc2, P.Lc2, k, nq, r2i, r2d, NULL, (u32)q0, out_i, out_d, k, 0, s);
   }
+  seg_mark(ix, marks, s);
   widen_ids_kernel<<<grid_for(Q * k, 256, 1u << 30), 256, 0, s>>>(Q * k, out_i, ids_dev);
   HIPCHECK(hipGetLastError());
+  seg_mark(ix, marks, s);
+  if (marks) ix->seg_used.push_back(marks_store);
   ix->queries += (double)Q;
   return nflag;
 }
@@ -669,7 +708,7 @@ extern "C" long annhip_stage1_finalize(annhip_index *ix, size_t Q, const ftype *
     HIPCHECK(hipMemcpy(ix->d_rows + 2, &cur, sizeof cur, hipMemcpyHostToDevice));
     return (long)Q;
   }
-  HIPCHECK(hipMemsetAsync(ix->d_fcount, 0, sizeof(u32), s));
+  zero_u32_kernel<<<1, 1, 0, s>>>(ix->d_fcount);
   hipLaunchKernelGGL(finalize1_kernel, dim3(grid_for(Q, 256, 1u << 30)), dim3(256), 0, s, (int)Q, P.k, P.k + 1, P.L1,
                      P.P1, reinterpret_cast<const FT *>(cand_dist_dev), cand_id_dev, nvalid_dev, top_id_dev,
                      reinterpret_cast<FT *>(top_dist_dev), P.k, 0, flagged_dev, ix->d_fcount, ix->d_rows + 2);
@@ -739,6 +778,16 @@ extern "C" void annhip_stats(annhip_index *ix, double out[8], int reset) {
     ix->ev_free.push_back(e);
   }
   ix->ev_used.clear();
+  for (auto &m : ix->seg_used) {
+    for (size_t i = 0; i + 1 < m.size() && i < 6; i++) {
+      float ms = 0;
+      HIPCHECK(hipEventSynchronize(m[i + 1]));
+      HIPCHECK(hipEventElapsedTime(&ms, m[i], m[i + 1]));
+      ix->seg_ms[i] += ms;
+    }
+    for (hipEvent_t e : m) ix->seg_free.push_back(e);
+  }
+  ix->seg_used.clear();
   unsigned long long rows[ANN_NCOUNTERS];
   HIPCHECK(hipMemcpy(rows, ix->d_rows, sizeof rows, hipMemcpyDeviceToHost));
   unsigned long long other = 0;
@@ -747,9 +796,17 @@ extern "C" void annhip_stats(annhip_index *ix, double out[8], int reset) {
   out[4] = (double)rows[2], out[5] = ix->queries, out[6] = out[7] = 0;
   if (reset) {
     ix->s1_launches = ix->s1_ms = ix->queries = 0;
+    for (double &v : ix->seg_ms) v = 0;
     HIPCHECK(hipMemset(ix->d_rows, 0, sizeof rows));
   }
 }
+
+extern "C" void annhip_stage_ms(annhip_index *ix, double out[6]) {
+  double dummy[8];
+  annhip_stats(ix, dummy, 0);  // resolves pending events
+  for (int i = 0; i < 6; i++) out[i] = ix->seg_ms[i];
+}
+
 
 // ----------------------------------------------------------------------------- precomp
 // rand_pr.c:8: uniform [0,1) from libc random()

@@ -364,14 +364,17 @@ __global__ __launch_bounds__(256) void row_dists_kernel(QParams P, int Q, const 
                                                         u32 *__restrict__ ids_out,
                                                         FT *__restrict__ dist_out,
                                                         unsigned long long *__restrict__ rows_done,
-                                                        const u32 *__restrict__ live_rows, u32 chunk) {
+                                                        const u32 *__restrict__ live_rows, u32 nrows,
+                                                        u32 chunk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // device-driven launches cover the worst case; rows beyond the device-side count leave at once
-  if (live_rows && blockIdx.x >= *live_rows) return;
+  // Device-driven launches (live_rows != NULL) use a small persistent grid that walks the device-side row
+  // count: launching one workgroup per POSSIBLE row just to exit cost ~50 us per launch at Q = 10k.
+  if (live_rows) nrows = min(nrows, *live_rows);
   const int lane = lane_id(), w = threadIdx.x >> 6, W = blockDim.x >> 6;
-  const u32 x = qidx ? qidx[blockIdx.x] : xbase + blockIdx.x;
-  u32 *ids_row = ids_out + (size_t)blockIdx.x * len;
-  FT *dist_row = dist_out + (size_t)blockIdx.x * len;
+  for (u32 row = blockIdx.x; row < nrows; row += gridDim.x) {
+  const u32 x = qidx ? qidx[row] : xbase + row;
+  u32 *ids_row = ids_out + (size_t)row * len;
+  FT *dist_row = dist_out + (size_t)row * len;
   unsigned char *sp = smem;
   u32 *lslot = reinterpret_cast<u32 *>(sp);           sp += sizeof(u32) * chunk;  // chunk <= ANN_RD_CHUNK
   u32 *lid = reinterpret_cast<u32 *>(sp);             sp += sizeof(u32) * chunk;
@@ -396,7 +399,8 @@ __global__ __launch_bounds__(256) void row_dists_kernel(QParams P, int Q, const 
     for (int c = 0; c < L::C; c++) a[c] = yp[c * L::LPR];
   }
   u32 gathered = 0;
-  for (u32 c0 = 0; c0 < len; c0 += chunk) {
+  // gridDim.y workgroups share one row: each takes every gridDim.y-th chunk of its slots
+  for (u32 c0 = blockIdx.y * chunk; c0 < len; c0 += gridDim.y * chunk) {
     const u32 c1 = min(len, c0 + chunk);
     if (threadIdx.x == 0) lcount[0] = 0;
     __syncthreads();
@@ -460,7 +464,9 @@ __global__ __launch_bounds__(256) void row_dists_kernel(QParams P, int Q, const 
   }
   // statistics: 64 counters on separate 64-byte lines; one counter for every workgroup would serialise the
   // launch behind ~12 ns per atomic (measured: +110 us on a 10k-row launch)
-  if (rows_done && threadIdx.x == 0) atomicAdd(&rows_done[(blockIdx.x & 63u) * 8u], (unsigned long long)gathered);
+  if (rows_done && threadIdx.x == 0) atomicAdd(&rows_done[(row & 63u) * 8u], (unsigned long long)gathered);
+  __syncthreads();  // LDS is re-used by the next row of this workgroup
+  }
 }
 
 // ----------------------------------------------------------------------------------- exact_select
@@ -468,34 +474,38 @@ __global__ __launch_bounds__(256) void row_dists_kernel(QParams P, int Q, const 
 // entries out.  One workgroup per row.  USE_LDS: the row is staged in LDS, otherwise the network runs in
 // place in global memory (rows too long for LDS; the workgroup owns the row).
 template <bool USE_LDS>
-__global__ __launch_bounds__(256) void exact_select_kernel(u32 L, u32 len, u32 in_stride, int k,
+__global__ __launch_bounds__(1024) void exact_select_kernel(u32 L, u32 len, u32 in_stride, int k,
                                                            u32 *__restrict__ ids_in,
                                                            FT *__restrict__ dist_in,
                                                            const u32 *__restrict__ qidx, u32 xbase,
                                                            u32 *__restrict__ out_id,
                                                            FT *__restrict__ out_dist, int ostride,
-                                                           int ooff, const u32 *__restrict__ live_rows) {
+                                                           int ooff, const u32 *__restrict__ live_rows,
+                                                           u32 nrows) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  if (live_rows && blockIdx.x >= *live_rows) return;
-  const u32 x = qidx ? qidx[blockIdx.x] : xbase + blockIdx.x;
-  u32 *gi = ids_in + (size_t)blockIdx.x * in_stride;
-  FT *gd = dist_in + (size_t)blockIdx.x * in_stride;
+  if (live_rows) nrows = min(nrows, *live_rows);  // persistent grid over the device-side row count
+  for (u32 row = blockIdx.x; row < nrows; row += gridDim.x) {
+  const u32 x = qidx ? qidx[row] : xbase + row;
+  u32 *gi = ids_in + (size_t)row * in_stride;
+  FT *gd = dist_in + (size_t)row * in_stride;
   if (USE_LDS) {
     FT *sd = reinterpret_cast<FT *>(smem);
     u32 *si = reinterpret_cast<u32 *>(sd + len);
     for (u32 j = threadIdx.x; j < len; j += blockDim.x) sd[j] = gd[j], si[j] = gi[j];
     __syncthreads();
-    block_topk_stage(L, len, sd, si);
+    block_topk_stage<true>(L, len, sd, si);
     for (int t = threadIdx.x; t < k; t += blockDim.x) {
       out_id[(size_t)x * ostride + ooff + t] = si[t];
       out_dist[(size_t)x * ostride + ooff + t] = sd[t];
     }
   } else {
-    block_topk_stage(L, len, gd, gi);
+    block_topk_stage<false>(L, len, gd, gi);
     for (int t = threadIdx.x; t < k; t += blockDim.x) {
       out_id[(size_t)x * ostride + ooff + t] = gi[t];
       out_dist[(size_t)x * ostride + ooff + t] = gd[t];
     }
+  }
+  __syncthreads();
   }
 }
 

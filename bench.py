@@ -133,6 +133,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     st = ix.stats()
+    stage_ms = ix.stage_ms() if world == 1 else None
     ix.profile(False)
 
     # ---- roofline of the dominant kernel (stage1_select): algorithmic bytes / HIP-event time
@@ -158,6 +159,8 @@ def main():
                        "exact_path_queries_per_step": round(st["exact_queries"] / args.steps, 2),
                        "host_submit_ms_per_step": round(submit_s / args.steps * 1e3, 4)},
             "roofline": roofline}
+    if stage_ms:
+        line["config"]["stage_ms_per_step"] = {k_: round(v / args.steps, 4) for k_, v in stage_ms.items()}
 
     # ---- CPU baseline + full-size parity sample (rank 0, single GPU only)
     if world == 1 and rank == 0 and not args.no_cpu_baseline:

@@ -109,6 +109,9 @@ void annhip_profile(annhip_index *ix, int profile);
  * profiling), out[4]=queries through the exact path, out[5]=queries seen; counters accumulate since the last
  * reset (reset != 0 clears them after reading). */
 void annhip_stats(annhip_index *ix, double out[8], int reset);
+/* While profiling, annhip_query also drops HIP events at its stage boundaries; out[0..5] = accumulated ms of
+ * hash codes, stage-1 kernel, finalize + exact fallback, stage-2 rows, stage-2 network, id widening. */
+void annhip_stage_ms(annhip_index *ix, double out[6]);
 
 #ifdef __cplusplus
 }
