@@ -148,6 +148,15 @@ def main():
                 "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
                 "rows_gathered_per_query": round(v1, 1)}
 
+    # PMC traffic cannot be read in-process; for the default workload it comes from the committed rocprofv3 passes
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if world == 1 and (n, d, k, T, Q) == (10_000_000, 128, 10, 10, 10_000):
+            roofline["traffic"] = tr["traffic_bytes_per_launch"]
+            roofline["traffic_source"] = tr["source"]
+    except (OSError, ValueError, KeyError):
+        pass
+
     value = Q * args.steps / elapsed
     line = {"metric": "queries/sec, N=10M d=128 k=10 Q=10k float (query(): hash + candidate gather + L2 + top-k + refine)",
             "value": round(value, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
