@@ -157,6 +157,8 @@ struct annhip_index {
   FT *d_points = NULL;
   bool own_points = false;
   std::vector<u32 *> d_tabs;  // per try
+  std::vector<uint2 *> d_segs;  // per try: per-bucket (first owned position, owned count, valid count)
+  bool use_seg = true;          // false when a table does not have the sorted-prefix layout (foreign save_t)
   std::vector<TryInfo> h_tries;
   TryInfo *d_tries = NULL;
   u32 *d_graph = NULL;
@@ -224,6 +226,24 @@ static void finish_geometry(annhip_index *ix) {
   }
 }
 
+// (re)build the per-bucket segment words of every try for the current owned range; decides use_seg
+static void build_segments(annhip_index *ix) {
+  const size_t nb = (size_t)1 << ix->ds;
+  u32 *bad = dev_alloc<u32>(1);
+  HIPCHECK(hipMemset(bad, 0, sizeof(u32)));
+  ix->d_segs.resize(ix->T, NULL);
+  for (int t = 0; t < ix->T; t++) {
+    if (!ix->d_segs[t]) ix->d_segs[t] = dev_alloc<uint2>(nb);
+    build_seg_kernel<<<grid_for(nb, 256, 1u << 30), 256>>>(nb, ix->h_tries[t].pm, ix->d_tabs[t], (u32)ix->n, (u32)ix->lo,
+                                                           (u32)ix->hi, ix->d_segs[t], bad);
+    ix->h_tries[t].seg = ix->d_segs[t];
+  }
+  u32 nbad = 0;
+  HIPCHECK(hipMemcpy(&nbad, bad, sizeof(u32), hipMemcpyDeviceToHost));
+  HIPCHECK(hipFree(bad));
+  ix->use_seg = nbad == 0 && !getenv("ANN_HIP_SLOT_SCAN");
+}
+
 static void check_limits(size_t n, size_t k, size_t d, size_t ds, int T) {
   if (n >= 0xFFFFFFF0ull) die("n must fit 32-bit ids on the device");
   if (k < 1 || n <= k) die("need n > k >= 1");
@@ -277,6 +297,7 @@ extern "C" annhip_index *annhip_index_create(const save_t *save, const ftype *po
   HIPCHECK(hipMemcpy(ix->d_means, save->row_means, sizeof(FT) * ix->d, hipMemcpyHostToDevice));
   ix->d_bases = dev_alloc<FT>((size_t)ix->T * ix->ds * ix->d);
   HIPCHECK(hipMemcpy(ix->d_bases, save->bases, sizeof(FT) * ix->T * ix->ds * ix->d, hipMemcpyHostToDevice));
+  build_segments(ix);
   finish_geometry(ix);
   return ix;
 }
@@ -288,6 +309,8 @@ extern "C" void annhip_index_reshard(annhip_index *ix, const ftype *shard_points
   ix->own_points = false;
   ix->d_points = const_cast<FT *>(reinterpret_cast<const FT *>(shard_points_dev));
   ix->lo = row_lo, ix->hi = row_hi;
+  build_segments(ix);  // the owned segment of every bucket moves with the row range
+  HIPCHECK(hipMemcpy(ix->d_tries, ix->h_tries.data(), sizeof(TryInfo) * ix->T, hipMemcpyHostToDevice));
 }
 
 extern "C" void annhip_index_destroy(annhip_index *ix) {
@@ -296,6 +319,8 @@ extern "C" void annhip_index_destroy(annhip_index *ix) {
   if (ix->own_points && ix->d_points) HIPCHECK(hipFree(ix->d_points));
   for (u32 *t : ix->d_tabs)
     if (t) HIPCHECK(hipFree(t));
+  for (uint2 *sg : ix->d_segs)
+    if (sg) HIPCHECK(hipFree(sg));
   if (ix->d_tries) HIPCHECK(hipFree(ix->d_tries));
   if (ix->d_graph) HIPCHECK(hipFree(ix->d_graph));
   if (ix->d_means) HIPCHECK(hipFree(ix->d_means));
@@ -417,10 +442,13 @@ static void launch_codes(const QParams &P, size_t Qhash, const FT *y, u32 *codes
   HIPCHECK(hipGetLastError());
 }
 
-static int stage1_waves(u32 P1) {
+// waves per query: enough slots per wave to amortise the per-wave selection and merge; a shard that owns a
+// small part of the rows gathers few rows per query and is better off with one wave (measured at 1/8: 1.87 -> 1.55 ms)
+static int stage1_waves(u32 P1, double own_frac) {
   int w = (int)(P1 / ANN_S1_CHUNK);
   if (w < 1) w = 1;
   if (w > 4) w = 4;
+  if (own_frac < 0.2) w = 1;
   const char *e = getenv("ANN_HIP_S1_WAVES");
   if (e && atoi(e) >= 1 && atoi(e) <= 4) w = atoi(e);
   return w;
@@ -433,8 +461,8 @@ static int stage1_cap(int W, int K1) {
 }
 static size_t stage1_lds_bytes(const QParams &P, int W, int K1, int cap) {
   size_t b = sizeof(Key) * (size_t)W * cap + 2 * sizeof(Key) * (size_t)W * K1 + sizeof(TryInfo) * (size_t)P.T +
-             sizeof(u32) * (size_t)W * ANN_S1_CHUNK + sizeof(u32) * (size_t)P.T + sizeof(int) * (size_t)W +
-             sizeof(u32) * 2;
+             sizeof(u32 *) * (size_t)W * ANN_WAVE + sizeof(u32) * (size_t)W * ANN_S1_CHUNK +
+             sizeof(u32) * (size_t)W * ANN_WAVE + sizeof(u32) * (size_t)P.T + sizeof(int) * (size_t)W + sizeof(u32) * 2;
   b = (b + 15) & ~(size_t)15;
   if (!d_is_fast(P.d)) b += sizeof(FT) * (size_t)P.d * (1 + W);
   return b;
@@ -454,11 +482,14 @@ __global__ void sum_u32_kernel(size_t count, const u32 *__restrict__ v, unsigned
 
 static void launch_stage1(annhip_index *ix, const QParams &P, size_t Q, const FT *y, int alias,
                           const u32 *codes, FT *cand_d, u32 *cand_i, u32 *nvt, u32 *nvo, hipStream_t s,
-                          bool stream_rows = true) {
+                          const std::vector<TryInfo> &h_tries, bool use_seg) {
   if (!Q) return;
-  if (getenv("ANN_HIP_CACHED_ROWS")) stream_rows = false;  // A/B switch: plain (cached) row loads
-  const int K1 = P.k + 1, W = stage1_waves(P.P1), cap = stage1_cap(W, K1);
+  const int K1 = P.k + 1, W = stage1_waves(P.P1, (double)(P.hi - P.lo) / (double)P.n), cap = stage1_cap(W, K1);
   const size_t smem = stage1_lds_bytes(P, W, K1, cap);
+  u32 runs_used = 0;  // (try, hamming neighbour) runs that start below P1, in slot order
+  for (int t = 0; t < P.T; t++)
+    for (int yy = 0; yy <= P.ds; yy++)
+      if (h_tries[t].off + (u32)yy * h_tries[t].pm < P.P1) runs_used++;
   EventPair ev;
   const bool prof = ix && ix->profile;
   if (prof) {
@@ -473,14 +504,14 @@ static void launch_stage1(annhip_index *ix, const QParams &P, size_t Q, const FT
   }
 #define CALL(DD)                                                                                            \
   do {                                                                                                      \
-    if (stream_rows) {                                                                                      \
+    if (use_seg) {                                                                                          \
       allow_lds(stage1_select_kernel<DD, true>, smem);                                                      \
       hipLaunchKernelGGL((stage1_select_kernel<DD, true>), dim3((unsigned)Q), dim3(64 * W), smem, s, P, (int)Q, y, \
-                         alias, codes, K1, cap, cand_d, cand_i, nvt, nvo);                                  \
+                         alias, codes, K1, cap, runs_used, cand_d, cand_i, nvt, nvo);                       \
     } else {                                                                                                \
       allow_lds(stage1_select_kernel<DD, false>, smem);                                                     \
       hipLaunchKernelGGL((stage1_select_kernel<DD, false>), dim3((unsigned)Q), dim3(64 * W), smem, s, P, (int)Q, y, \
-                         alias, codes, K1, cap, cand_d, cand_i, nvt, nvo);                                  \
+                         alias, codes, K1, cap, runs_used, cand_d, cand_i, nvt, nvo);                       \
     }                                                                                                       \
   } while (0)
   ANN_DISPATCH_D(P.d, CALL);
@@ -646,7 +677,7 @@ extern "C" long annhip_query(annhip_index *ix, size_t Q, const ftype *y_dev, int
     cand_i = (u32 *)ix->cand_i.need(sizeof(u32) * Q * K1);
     nvt = (u32 *)ix->nvt.need(sizeof(u32) * Q);
     u32 *nvo = (u32 *)ix->nvo.need(sizeof(u32) * Q);
-    launch_stage1(ix, P, Q, y, alias, codes, cand_d, cand_i, nvt, nvo, s);
+    launch_stage1(ix, P, Q, y, alias, codes, cand_d, cand_i, nvt, nvo, s, ix->h_tries, ix->use_seg);
   }
   seg_mark(ix, marks, s);
   unsigned long long *rows_ctr = ix->profile ? ix->d_rows + 8 : NULL;
@@ -687,7 +718,7 @@ extern "C" void annhip_stage1_local(annhip_index *ix, size_t Q, const ftype *y_d
   const QParams P = make_params(ix);
   u32 *nvo = (u32 *)ix->nvo.need(sizeof(u32) * Q);
   launch_stage1(ix, P, Q, reinterpret_cast<const FT *>(y_dev), alias, codes_dev, reinterpret_cast<FT *>(cand_dist_dev),
-                cand_id_dev, nvalid_dev, nvo, ix->stream);
+                cand_id_dev, nvalid_dev, nvo, ix->stream, ix->h_tries, ix->use_seg);
   ix->queries += (double)Q;
 }
 
@@ -944,6 +975,9 @@ extern "C" annhip_index *annhip_precomp_index(size_t n, size_t k, size_t d, cons
   u32 *cnt = dev_alloc<u32>(nb), *cursor = dev_alloc<u32>(nb), *d_max_cnt = dev_alloc<u32>(1);
   ix->h_tries.resize(T);
   ix->d_tabs.resize(T);
+  ix->d_segs.assign(T, NULL);
+  u32 *d_bad = dev_alloc<u32>(1);
+  HIPCHECK(hipMemset(d_bad, 0, sizeof(u32)));
   ix->d_fcount = dev_alloc<u32>(4);
   ix->d_rows = dev_alloc<unsigned long long>(ANN_NCOUNTERS);
   HIPCHECK(hipMemset(ix->d_rows, 0, ANN_NCOUNTERS * sizeof(unsigned long long)));
@@ -967,9 +1001,14 @@ extern "C" annhip_index *annhip_precomp_index(size_t n, size_t k, size_t d, cons
     ix->d_tabs[t] = tab;
     ix->h_tries[t].tab = tab;
     ix->h_tries[t].pm = pm;
+    if (pm > 0xFFFFu) die("bucket too large");
+    ix->d_segs[t] = dev_alloc<uint2>(nb);
+    build_seg_kernel<<<grid_for(nb, 256, 1u << 30), 256, 0, s>>>(nb, pm, tab, (u32)n, 0u, (u32)n, ix->d_segs[t], d_bad);
+    ix->h_tries[t].seg = ix->d_segs[t];
 
     // a one-try view of the index: candidate row = [ds+1][pm], codes are the points' own (no scramble)
     TryInfo one;
+    one.seg = ix->d_segs[t];
     one.tab = tab, one.pm = pm, one.off = 0, one.end = (u32)((ds + 1) * pm), one.magic = magic_for(pm);
     if ((unsigned long long)one.end * pm >= (1ull << 32)) die("candidate row too long");
     HIPCHECK(hipMemcpyAsync(solo, &one, sizeof one, hipMemcpyHostToDevice, s));
@@ -986,7 +1025,7 @@ extern "C" annhip_index *annhip_precomp_index(size_t n, size_t k, size_t d, cons
       ci = (u32 *)cand_i.need(sizeof(u32) * n * (k + 1));
       nv = (u32 *)nvt.need(sizeof(u32) * n);
       u32 *no = (u32 *)nvo.need(sizeof(u32) * n);
-      launch_stage1(NULL, P, n, pts, 1, codes[t], cd, ci, nv, no, s, getenv("ANN_HIP_CACHED_ROWS") == NULL);
+      launch_stage1(NULL, P, n, pts, 1, codes[t], cd, ci, nv, no, s, std::vector<TryInfo>(1, one), !getenv("ANN_HIP_SLOT_SCAN"));
     }
     finalize_and_fallback(NULL, P, n, pts, 1, codes[t], mode, cd, ci, nv, merged_i, merged_d, (int)W, (int)(t * k),
                           flist, xids, xd, ix->d_fcount, NULL, NULL, false, s);
@@ -997,6 +1036,13 @@ extern "C" annhip_index *annhip_precomp_index(size_t n, size_t k, size_t d, cons
   HIPCHECK(hipFree(cursor));
   HIPCHECK(hipFree(d_max_cnt));
   HIPCHECK(hipFree(solo));
+  {
+    u32 nbad = 0;
+    HIPCHECK(hipMemcpy(&nbad, d_bad, sizeof(u32), hipMemcpyDeviceToHost));
+    HIPCHECK(hipFree(d_bad));
+    if (nbad) die("internal error: a bucket table built by precomp is not in sorted-prefix layout");
+    ix->use_seg = !getenv("ANN_HIP_SLOT_SCAN");
+  }
   cand_d.release(), cand_i.release(), nvt.release(), nvo.release(), flist.release(), xids.release(), xd.release();
 
   // det_results on the merged rows (alg.c:419-422): distances are reused, graph == merged rows (Q16)

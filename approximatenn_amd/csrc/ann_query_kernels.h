@@ -20,6 +20,7 @@
 
 struct TryInfo {   // one try (= one random projection) of the index
   const u32 *tab;  // [2^ds][pm] bucket table, ids descending then padding n  (alg.c:261-266)
+  const uint2 *seg;  // [2^ds] per bucket: x = first owned position | owned count << 16, y = valid count (see build_seg_kernel)
   u32 pm;          // par_maxes[t]
   u32 off;         // first slot of this try's block in the candidate row     (alg.c:484-488,449)
   u32 end;         // off + (ds+1)*pm
@@ -137,17 +138,137 @@ __device__ __forceinline__ u32 slot_id(const TryInfo *tries, const u32 *qcode, u
 }
 
 // ---------------------------------------------------------------------------------- stage1_select
-// One workgroup per query; its waves split the first P1 slots of the candidate row.  Per wave:
-//   A) read a chunk of slot ids, keep the valid ones this device owns in an LDS list (ballot compaction);
-//   B) gather those rows (LPR lanes per row, 16-byte chunks, next pass prefetched), squared L2 in the
-//      reference's tree order, keep keys below the running (k+1)-th smallest in an LDS buffer, and shrink
-//      that buffer with wave_select_smallest whenever it fills.
-// The waves' survivors are merged by wave 0.  Output per query: K1 = k+1 ascending distinct keys (padded
-// with (+inf, ANN_ID_NONE)), the number of valid slots (for the +inf test of finalize1) and of gathered rows.
-template <int D, bool NT>
+// Bucket rows hold their ids in descending order followed by padding (Q8), so (a) the valid ids of a bucket are
+// a prefix and (b) the ids a device owns (a contiguous id range) are ONE contiguous segment of the row.
+// build_seg_kernel records, per bucket, where that segment starts, how long it is, and how many valid ids the
+// bucket has.  The scan of stage 1 then touches only ids it will gather instead of every slot: at cfg3
+// 168 segment words + 1.4k ids per query instead of 4096 slot ids (and 1/G of the ids on each of G shards).
+// It also verifies the layout assumption; a table that violates it (not produced by precomp) sets *bad and the
+// host falls back to the slot scan.
+__global__ void build_seg_kernel(size_t nbuckets, u32 pm, const u32 *__restrict__ tab, u32 n, u32 lo, u32 hi,
+                                 uint2 *__restrict__ seg, u32 *__restrict__ bad) {
+  const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbuckets) return;
+  const u32 *row = tab + b * pm;
+  u32 ca = 0, zs = 0, co = 0, prev = 0xFFFFFFFFu;
+  bool ok = true, ended = false, own_ended = false;
+  for (u32 z = 0; z < pm; z++) {
+    const u32 id = row[z];
+    if (id >= n) {
+      ended = true;
+      continue;
+    }
+    if (ended || id >= prev) ok = false;  // valid ids must be a strictly descending prefix
+    prev = id;
+    ca++;
+    if (id >= lo && id < hi) {
+      if (own_ended) ok = false;
+      if (!co) zs = z;
+      co++;
+    } else if (co) {
+      own_ended = true;
+    }
+  }
+  if (!ok || pm > 0xFFFFu) atomicAdd(bad, 1u);
+  seg[b] = make_uint2(zs | (co << 16), ca);
+}
+
+__device__ __forceinline__ u32 wave_incl_scan(u32 v) {
+#pragma unroll
+  for (int o = 1; o < ANN_WAVE; o <<= 1) {
+    u32 t = __shfl_up(v, o);
+    if (lane_id() >= o) v += t;
+  }
+  return v;
+}
+
+// Per-wave state of the running selection of the k+1 smallest distinct keys.
+struct SelState {
+  Key *kbuf, *kout;  // LDS: cap keys / K1 keys
+  int kcnt, K1, cap;
+  Key tau;           // keys >= tau cannot be among the k+1 smallest any more
+};
+
+__device__ __forceinline__ void sel_shrink(SelState &S) {
+  wave_lds_sync();
+  const int m = wave_select_smallest(S.kbuf, S.kcnt, S.K1, S.kout);
+  for (int i = lane_id(); i < m; i += ANN_WAVE) S.kbuf[i] = S.kout[i];
+  if (m == S.K1) S.tau = S.kout[S.K1 - 1];
+  S.kcnt = m;
+  wave_lds_sync();
+}
+
+// B) gather the rows listed in list[0..cnt) (LDS), squared L2 to the query in the reference's tree order, keep
+// the keys that can still matter.  D > 0: LPR lanes per row, the next pass is prefetched while this one is reduced.
+template <int D>
+__device__ __forceinline__ void gather_select(const QParams &P, const u32 *list, int cnt, int alias, u32 x,
+                                              const VT (&a)[D > 0 ? RowLay<(D > 0 ? D : 16)>::C : 1],
+                                              const FT *yq, FT *scratch, SelState &S) {
+  const int lane = lane_id();
+  if constexpr (D > 0) {
+    typedef RowLay<D> L;
+    const int p = lane % L::LPR, g = lane / L::LPR;
+    VT bn[L::C];
+    u32 idn = 0;
+    if (cnt > 0) {
+      idn = list[g < cnt ? g : 0];
+      const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(idn - P.lo) * D) + p;
+#pragma unroll
+      for (int c = 0; c < L::C; c++) bn[c] = load_row_chunk<true>(rp + c * L::LPR);
+    }
+    for (int base = 0; base < cnt; base += L::RPW) {
+      VT b[L::C];
+#pragma unroll
+      for (int c = 0; c < L::C; c++) b[c] = bn[c];
+      const u32 id = idn;
+      const bool act = base + g < cnt && !(alias && id == x);
+      const int nb = base + L::RPW;
+      if (nb < cnt) {
+        idn = list[nb + g < cnt ? nb + g : nb];
+        const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(idn - P.lo) * D) + p;
+#pragma unroll
+        for (int c = 0; c < L::C; c++) bn[c] = load_row_chunk<true>(rp + c * L::LPR);
+      }
+      const FT dist = row_reduce<D, ROW_SQDIFF>(a, b);
+      const Key key = key_make(dist, id);
+      const bool pass = act && p == 0 && key_less(key, S.tau);
+      const u64 mm = __ballot(pass);
+      if (mm) {
+        if (pass) S.kbuf[S.kcnt + mask_rank(mm)] = key;
+        S.kcnt += __popcll(mm);
+        if (S.kcnt + L::RPW > S.cap) sel_shrink(S);
+      }
+    }
+  } else {
+    for (int r = 0; r < cnt; r++) {
+      const u32 id = list[r];
+      if (alias && id == x) continue;  // wave-uniform
+      const FT dist = row_reduce_generic<ROW_SQDIFF>(P.d, yq, P.points + (size_t)(id - P.lo) * P.d, scratch);
+      const Key key = key_make(dist, id);
+      if (key_less(key, S.tau)) {  // wave-uniform
+        if (lane == 0) S.kbuf[S.kcnt] = key;
+        S.kcnt++;
+        if (S.kcnt + 1 > S.cap) sel_shrink(S);
+      }
+    }
+  }
+  wave_lds_sync();
+}
+
+// One workgroup per query; its waves split the work on the first P1 slots of the candidate row.  Per wave:
+//   A) SEG: for its share of the (try, hamming-neighbour) runs below P1, read the bucket's segment word and copy
+//      the owned ids into an LDS list (prefix sum over the lanes' counts, then a balanced copy);
+//      !SEG (fallback): read every slot id of its slice and ballot-compact the owned valid ones;
+//   B) gather_select on the list whenever it fills, and at the end.
+// The waves' survivors are merged by wave 0.  Output per query: K1 = k+1 ascending distinct keys (padded with
+// (+inf, ANN_ID_NONE)); nv_tot = valid slots below P1 on ANY device -- with SEG an upper bound that ignores the
+// self exclusion (only used for finalize1's "is there an +inf in the prefix" test, where an over-estimate merely
+// sends a query to the exact path); nv_own = rows this device gathered.
+template <int D, bool SEG>
 __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, const FT *__restrict__ y,
                                                             int alias, const u32 *__restrict__ codes,
-                                                            int K1, int cap, FT *__restrict__ cand_dist,
+                                                            int K1, int cap, u32 runs_used,
+                                                            FT *__restrict__ cand_dist,
                                                             u32 *__restrict__ cand_id,
                                                             u32 *__restrict__ nv_tot,
                                                             u32 *__restrict__ nv_own) {
@@ -160,14 +281,17 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
   Key *kout_all = reinterpret_cast<Key *>(sp);           sp += sizeof(Key) * (size_t)W * K1;
   Key *mbuf = reinterpret_cast<Key *>(sp);               sp += sizeof(Key) * (size_t)W * K1;
   TryInfo *tries = reinterpret_cast<TryInfo *>(sp);      sp += sizeof(TryInfo) * (size_t)P.T;
+  const u32 **rptr_all = reinterpret_cast<const u32 **>(sp);  sp += sizeof(u32 *) * (size_t)W * ANN_WAVE;
   u32 *list_all = reinterpret_cast<u32 *>(sp);           sp += sizeof(u32) * (size_t)W * ANN_S1_CHUNK;
+  u32 *pref_all = reinterpret_cast<u32 *>(sp);           sp += sizeof(u32) * (size_t)W * ANN_WAVE;
   u32 *qcode = reinterpret_cast<u32 *>(sp);              sp += sizeof(u32) * (size_t)P.T;
   int *mcnt = reinterpret_cast<int *>(sp);               sp += sizeof(int) * (size_t)W;
   u32 *cnts = reinterpret_cast<u32 *>(sp);               sp += sizeof(u32) * 2;
   sp = smem + (((sp - smem) + 15) & ~(size_t)15);
   FT *yq = reinterpret_cast<FT *>(sp);  // generic d only: [d] + W*[d]
-  Key *kbuf = kbuf_all + (size_t)w * cap, *kout = kout_all + (size_t)w * K1;
   u32 *list = list_all + (size_t)w * ANN_S1_CHUNK;
+  u32 *pref = pref_all + (size_t)w * ANN_WAVE;
+  const u32 **rptr = rptr_all + (size_t)w * ANN_WAVE;
 
   for (int i = threadIdx.x; i < P.T; i += blockDim.x) {
     tries[i] = P.tries[i];
@@ -178,12 +302,10 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
     for (int z = threadIdx.x; z < P.d; z += blockDim.x) yq[z] = y[(size_t)x * P.d + z];
   __syncthreads();
 
-  // this wave's slice of [0, P1)
-  const u32 per = (((P.P1 + W - 1) / W) + 63u) & ~63u;
-  const u32 s0 = min(P.P1, (u32)w * per), s1 = min(P.P1, s0 + per);
-
-  Key tau = key_max();
-  int kcnt = 0;
+  SelState S;
+  S.kbuf = kbuf_all + (size_t)w * cap, S.kout = kout_all + (size_t)w * K1;
+  S.kcnt = 0, S.K1 = K1, S.cap = cap, S.tau = key_max();
+  FT *scratch = yq + (size_t)(1 + w) * P.d;
   u32 vtot = 0, vown = 0;
 
   // the query row, as this lane's slice
@@ -195,93 +317,87 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
     for (int c = 0; c < L::C; c++) a[c] = yp[c * L::LPR];
   }
 
-  for (u32 c0 = s0; c0 < s1; c0 += ANN_S1_CHUNK) {
-    const u32 c1 = min(s1, c0 + ANN_S1_CHUNK);
-    // ---- A: slot ids -> compact list of owned valid ids
-    int cnt = 0, ti = 0;
-    for (u32 base = c0; base < c1; base += ANN_WAVE) {
+  int cnt = 0;
+  if constexpr (SEG) {
+    const u32 ds1 = (u32)P.ds + 1u;
+    const u32 per = (runs_used + W - 1) / W;  // runs of this wave: [r0, r1)
+    const u32 r0 = min(runs_used, (u32)w * per), r1 = min(runs_used, r0 + per);
+    for (u32 rb = r0; rb < r1; rb += ANN_WAVE) {
+      const u32 r = rb + lane;
+      u32 c = 0, va = 0;
+      const u32 *src = NULL;
+      if (r < r1) {
+        const u32 i = r / ds1, yy = r - i * ds1;
+        const TryInfo tr = tries[i];
+        const u32 b = qcode[i] ^ (yy ? 1u << (yy - 1) : 0u);  // compute_which, compute.cl:243-245
+        const uint2 sg = tr.seg[b];
+        const u32 zs = sg.x & 0xFFFFu, co = sg.x >> 16, ca = sg.y;
+        const u32 zlim = min(tr.pm, P.P1 - (tr.off + yy * tr.pm));  // slots of this run below P1 (Q1)
+        va = min(ca, zlim);
+        const u32 ze = min(zs + co, zlim);
+        c = ze > zs ? ze - zs : 0u;
+        src = tr.tab + (size_t)b * tr.pm + zs;
+      }
+      vtot += va;
+      const u32 incl = wave_incl_scan(c);
+      const u32 total = __shfl(incl, ANN_WAVE - 1);
+      pref[lane] = incl - c;
+      rptr[lane] = src;
+      wave_lds_sync();
+      for (u32 done = 0; done < total;) {  // balanced copy of `total` ids into the list, list-capacity pieces
+        const u32 take = min((u32)ANN_S1_CHUNK - (u32)cnt, total - done);
+        for (u32 e = done + lane; e < done + take; e += ANN_WAVE) {
+          int lo_ = 0, hi_ = ANN_WAVE - 1;  // last run j with pref[j] <= e (it has c_j > 0)
+          while (lo_ < hi_) {
+            const int mid = (lo_ + hi_ + 1) >> 1;
+            if (pref[mid] <= e) lo_ = mid; else hi_ = mid - 1;
+          }
+          list[cnt + (e - done)] = rptr[lo_][e - pref[lo_]];
+        }
+        cnt += take, done += take;
+        if (cnt == ANN_S1_CHUNK) {
+          wave_lds_sync();
+          vown += cnt;
+          gather_select<D>(P, list, cnt, alias, x, a, yq, scratch, S);
+          cnt = 0;
+        }
+      }
+      wave_lds_sync();
+    }
+    // one wave-level sum of the per-lane valid counts
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) vtot += __shfl_xor(vtot, m);
+  } else {
+    // fallback: every slot of this wave's slice of [0, P1)
+    const u32 per = (((P.P1 + W - 1) / W) + 63u) & ~63u;
+    const u32 s0 = min(P.P1, (u32)w * per), s1 = min(P.P1, s0 + per);
+    int ti = 0;
+    for (u32 base = s0; base < s1; base += ANN_WAVE) {
       const u32 j = base + lane;
       u32 id = ANN_ID_NONE;
-      if (j < c1) id = slot_id(tries, qcode, j, ti);
+      if (j < s1) id = slot_id(tries, qcode, j, ti);
       const bool ok = id < P.n && !(alias && id == x);
       const bool own = ok && id >= P.lo && id < P.hi;
       vtot += __popcll(__ballot(ok));
       const u64 mm = __ballot(own);
       if (own) list[cnt + mask_rank(mm)] = id;
       cnt += __popcll(mm);
-    }
-    vown += cnt;
-    wave_lds_sync();
-    // ---- B: gather + distance + running selection
-    if constexpr (D > 0) {
-      typedef RowLay<D> L;
-      const int p = lane % L::LPR, g = lane / L::LPR;
-      VT bn[L::C];
-      u32 idn = 0;
-      if (cnt > 0) {
-        idn = list[g < cnt ? g : 0];
-        const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(idn - P.lo) * D) + p;
-#pragma unroll
-        for (int c = 0; c < L::C; c++) bn[c] = load_row_chunk<NT>(rp + c * L::LPR);
-      }
-      for (int base = 0; base < cnt; base += L::RPW) {
-        VT b[L::C];
-#pragma unroll
-        for (int c = 0; c < L::C; c++) b[c] = bn[c];
-        const u32 id = idn;
-        const bool act = base + g < cnt;
-        const int nb = base + L::RPW;
-        if (nb < cnt) {  // prefetch the next pass while this one is reduced
-          idn = list[nb + g < cnt ? nb + g : nb];
-          const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(idn - P.lo) * D) + p;
-#pragma unroll
-          for (int c = 0; c < L::C; c++) bn[c] = load_row_chunk<NT>(rp + c * L::LPR);
-        }
-        const FT dist = row_reduce<D, ROW_SQDIFF>(a, b);
-        const Key key = key_make(dist, id);
-        const bool pass = act && p == 0 && key_less(key, tau);
-        const u64 mm = __ballot(pass);
-        if (mm) {
-          if (pass) kbuf[kcnt + mask_rank(mm)] = key;
-          kcnt += __popcll(mm);
-          if (kcnt + L::RPW > cap) {
-            wave_lds_sync();
-            const int m = wave_select_smallest(kbuf, kcnt, K1, kout);
-            for (int i = lane; i < m; i += ANN_WAVE) kbuf[i] = kout[i];
-            if (m == K1) tau = kout[K1 - 1];
-            kcnt = m;
-            wave_lds_sync();
-          }
-        }
-      }
-    } else {
-      FT *m = yq + (size_t)(1 + w) * P.d;
-      for (int r = 0; r < cnt; r++) {
-        const u32 id = list[r];
-        const FT dist = row_reduce_generic<ROW_SQDIFF>(P.d, yq, P.points + (size_t)(id - P.lo) * P.d, m);
-        const Key key = key_make(dist, id);
-        if (key_less(key, tau)) {  // wave-uniform
-          if (lane == 0) kbuf[kcnt] = key;
-          kcnt++;
-          if (kcnt + 1 > cap) {
-            wave_lds_sync();
-            const int mk = wave_select_smallest(kbuf, kcnt, K1, kout);
-            for (int i = lane; i < mk; i += ANN_WAVE) kbuf[i] = kout[i];
-            if (mk == K1) tau = kout[K1 - 1];
-            kcnt = mk;
-            wave_lds_sync();
-          }
-        }
+      if (cnt + ANN_WAVE > ANN_S1_CHUNK) {
+        wave_lds_sync();
+        vown += cnt;
+        gather_select<D>(P, list, cnt, alias, x, a, yq, scratch, S);
+        cnt = 0;
       }
     }
-    wave_lds_sync();
   }
+  wave_lds_sync();
+  vown += cnt;
+  gather_select<D>(P, list, cnt, alias, x, a, yq, scratch, S);
 
   // ---- this wave's survivors -> merge buffer
-  wave_lds_sync();
   {
-    const int m = wave_select_smallest(kbuf, kcnt, K1, kout);
-    for (int i = lane; i < m; i += ANN_WAVE) mbuf[(size_t)w * K1 + i] = kout[i];
+    const int m = wave_select_smallest(S.kbuf, S.kcnt, K1, S.kout);
+    for (int i = lane; i < m; i += ANN_WAVE) mbuf[(size_t)w * K1 + i] = S.kout[i];
     if (lane == 0) {
       mcnt[w] = m;
       atomicAdd(&cnts[0], vtot);
@@ -293,14 +409,14 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
     int total = 0;
     for (int ww = 0; ww < W; ww++) {  // cap >= W*K1 (host guarantees)
       const int m = mcnt[ww];
-      for (int i = lane; i < m; i += ANN_WAVE) kbuf[total + i] = mbuf[(size_t)ww * K1 + i];
+      for (int i = lane; i < m; i += ANN_WAVE) S.kbuf[total + i] = mbuf[(size_t)ww * K1 + i];
       total += m;
     }
     wave_lds_sync();
-    const int m = wave_select_smallest(kbuf, total, K1, kout);
+    const int m = wave_select_smallest(S.kbuf, total, K1, S.kout);
     for (int i = lane; i < K1; i += ANN_WAVE) {
-      cand_dist[(size_t)x * K1 + i] = i < m ? key_dist(kout[i]) : ft_inf();
-      cand_id[(size_t)x * K1 + i] = i < m ? key_id(kout[i]) : ANN_ID_NONE;
+      cand_dist[(size_t)x * K1 + i] = i < m ? key_dist(S.kout[i]) : ft_inf();
+      cand_id[(size_t)x * K1 + i] = i < m ? key_id(S.kout[i]) : ANN_ID_NONE;
     }
     if (lane == 0) {
       nv_tot[x] = cnts[0];
