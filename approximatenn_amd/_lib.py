@@ -74,6 +74,7 @@ def load(prec="f32"):
     lib.annhip_stage2_rows.argtypes = [vp, sz, vp, C.c_int, u32p, vp, u32p, vp]
     lib.annhip_exact_select.argtypes = [vp, C.c_int, sz, u32p, vp, u32p, u32p, vp]
     lib.annhip_widen_ids.argtypes = [vp, sz, u32p, vp]
+    lib.annhip_recall_ranks.argtypes = [sz, sz, sz, vp, sz, vp, vp, C.c_int, vp]
     lib.annhip_profile.argtypes = [vp, C.c_int]
     lib.annhip_stats.argtypes = [vp, C.POINTER(C.c_double * 8), C.c_int]
     lib.annhip_stage_ms.argtypes = [vp, C.POINTER(C.c_double * 6)]
@@ -94,5 +95,5 @@ EXPORTED = ["gpu_init", "gpu_cleanup", "register_cleanup", "query_gpu", "precomp
             "annhip_index_create", "annhip_index_destroy", "annhip_index_info", "annhip_index_set_stream",
             "annhip_index_export", "annhip_index_reshard", "annhip_save_write", "annhip_save_read", "annhip_precomp_index", "annhip_query", "annhip_codes", "annhip_stage1_local",
             "annhip_merge_candidates", "annhip_stage1_finalize", "annhip_stage1_rows", "annhip_stage2_rows", "annhip_exact_select",
-            "annhip_widen_ids", "annhip_profile", "annhip_stats", "annhip_stage_ms"]
+            "annhip_widen_ids", "annhip_recall_ranks", "annhip_profile", "annhip_stats", "annhip_stage_ms"]
 DISPATCH_EXPORTED = ["precomp", "query", "free_save"]

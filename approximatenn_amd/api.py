@@ -157,6 +157,30 @@ def query(save, points, y, want_dists=True):
     return ids, _take(dptr, ycnt * k, cft, _ft(prec)).reshape(ycnt, k)
 
 
+def recall_ranks(points, y, guess, self_exclude=False):
+    """annhip_recall_ranks: torch device tensors points [n,d], y [Q,d], guess int64 [Q,k] -> int64 ranks [Q,k]
+    (number of points strictly closer than each guessed neighbour)."""
+    import torch
+    prec = "f32" if points.dtype == torch.float32 else "f64"
+    lib = _lib.load(prec)
+    assert points.is_cuda and y.is_cuda and guess.is_cuda and guess.dtype == torch.int64
+    points, y, guess = points.contiguous(), y.contiguous(), guess.contiguous()
+    ranks = torch.empty(guess.shape, dtype=torch.int64, device=guess.device)
+    lib.annhip_recall_ranks(points.shape[0], points.shape[1], guess.shape[1], points.data_ptr(), y.shape[0], y.data_ptr(),
+                            guess.data_ptr(), int(self_exclude), ranks.data_ptr())
+    return ranks
+
+
+def recall_summary(ranks, k):
+    """The three numbers /root/reference/test_correctness.c:131-139 prints, from a rank tensor [Q,k]:
+    average index score (mean rank excess per neighbour), probability correct (rank < k), max index score / k."""
+    r = ranks.to("cpu").double()
+    per_query = r.sum(dim=1).mean().item()
+    return dict(avg_index_score=(per_query - k * (k - 1) / 2) / k,
+                prob_correct=1.0 - (r >= k).double().mean().item(),
+                max_index_score=r.max().item() / k)
+
+
 class Index:
     """A device-resident index (include/ann_hip.h).  Tensors are torch CUDA(HIP) tensors; torch is only the
     allocator and stream provider here."""

@@ -19,6 +19,7 @@
 #include "../../include/gpu_comp.h"
 #include "ann_precomp_kernels.h"
 #include "ann_query_kernels.h"
+#include "ann_recall_kernels.h"
 
 static_assert(sizeof(ftype) == sizeof(FT), "ftype.h and ann_device.h disagree on the precision");
 
@@ -838,6 +839,59 @@ extern "C" void annhip_stage_ms(annhip_index *ix, double out[6]) {
   for (int i = 0; i < 6; i++) out[i] = ix->seg_ms[i];
 }
 
+
+// ----------------------------------------------------------------------------- recall scoring
+// ranks_dev[q][j] = number of points strictly closer to query q than its j-th guess (0 = it is the nearest).
+// points_dev: ALL n rows; guess_dev: size_t[Q][k] as returned by query()/precomp(); self: skip point q for query q.
+extern "C" void annhip_recall_ranks(size_t n, size_t d, size_t k, const ftype *points_dev, size_t Q, const ftype *y_dev,
+                                    const size_t *guess_dev, int self, unsigned long long *ranks_dev) {
+  gpu_init();
+  if (!Q || !k) return;
+  if (n >= 0xFFFFFFF0ull) die("n must fit 32 bits");
+  const FT *pts = reinterpret_cast<const FT *>(points_dev), *y = reinterpret_cast<const FT *>(y_dev);
+  FT *gd = dev_alloc<FT>(Q * k);
+  unsigned long long *hist = dev_alloc<unsigned long long>(Q * (k + 1));
+  HIPCHECK(hipMemset(hist, 0, sizeof(unsigned long long) * Q * (k + 1)));
+  const int wpb = 4;
+  const bool fast = d_is_fast(d);
+  const size_t smem_g = fast ? 0 : sizeof(FT) * wpb * 2 * d;
+  const size_t smem_s = fast ? sizeof(FT) * ANN_RECALL_TILE * d : sizeof(FT) * wpb * 2 * d;
+  const unsigned tiles = (unsigned)((n + ANN_RECALL_TILE - 1) / ANN_RECALL_TILE);
+  unsigned qgroups = (unsigned)std::min<size_t>((Q + wpb - 1) / wpb, tiles < 2048 ? (4096 / (tiles ? tiles : 1)) + 1 : 1);
+  if (qgroups < 1) qgroups = 1;
+  if (qgroups > 65535) qgroups = 65535;
+#define CALL(DD)                                                                                                  \
+  do {                                                                                                            \
+    allow_lds(recall_guess_dist_kernel<DD>, smem_g);                                                              \
+    hipLaunchKernelGGL(recall_guess_dist_kernel<DD>, dim3((unsigned)((Q + wpb - 1) / wpb)), dim3(64 * wpb), smem_g, 0, \
+                       pts, (u32)n, (int)d, (int)Q, (int)k, y, guess_dev, gd);                                   \
+    allow_lds(recall_scan_kernel<DD>, smem_s);                                                                    \
+    hipLaunchKernelGGL(recall_scan_kernel<DD>, dim3(tiles, qgroups), dim3(64 * wpb), smem_s, 0, pts, (u32)n, (int)d, \
+                       (int)Q, (int)k, y, gd, self, hist);                                                        \
+  } while (0)
+  ANN_DISPATCH_D((int)d, CALL);
+#undef CALL
+  HIPCHECK(hipGetLastError());
+  // rank[j] = #points closer than guess j = sum of hist[c] over the c's whose point is closer than gdist[j]:
+  // a point counted in bin c has exactly c guesses at least as close as itself, so it is closer than guess j iff
+  // guess j is not among those c, i.e. (guesses ascending) iff c <= position of j.  Done on the host: tiny.
+  std::vector<unsigned long long> h(Q * (k + 1)), out(Q * k);
+  std::vector<FT> g(Q * k);
+  HIPCHECK(hipMemcpy(h.data(), hist, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+  HIPCHECK(hipMemcpy(g.data(), gd, sizeof(FT) * g.size(), hipMemcpyDeviceToHost));
+  for (size_t q = 0; q < Q; q++)
+    for (size_t j = 0; j < k; j++) {
+      // number of guesses strictly closer than guess j (works for unsorted guesses too)
+      size_t pos = 0;
+      for (size_t i = 0; i < k; i++) pos += g[q * k + i] < g[q * k + j];
+      unsigned long long r = 0;
+      for (size_t c = 0; c <= pos && c <= k; c++) r += h[q * (k + 1) + c];
+      out[q * k + j] = r;
+    }
+  HIPCHECK(hipMemcpy(ranks_dev, out.data(), sizeof(unsigned long long) * out.size(), hipMemcpyHostToDevice));
+  HIPCHECK(hipFree(gd));
+  HIPCHECK(hipFree(hist));
+}
 
 // ----------------------------------------------------------------------------- precomp
 // rand_pr.c:8: uniform [0,1) from libc random()

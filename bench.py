@@ -162,7 +162,8 @@ def main():
             "value": round(value, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "cfg3: N=%d d=%d k=%d tries=%d Q=%d/step float, randn points+queries" % (n, d, k, T, Q),
+            "config": {"workload": "%sN=%d d=%d k=%d tries=%d Q=%d/step float, randn points+queries"
+                       % ("cfg3: " if (n, d, k, args.q) == (10_000_000, 128, 10, 10_000) else "", n, d, k, T, Q),
                        "points_sharding": "rows/%d" % world, "d_short": ix.d_short, "L1": ix.L1, "P1": ix.P1,
                        "L2": ix.L2, "P2": ix.P2, "sum_par_maxes": ix.sum_pm, "precomp_s": round(precomp_s, 2),
                        "exact_path_queries_per_step": round(st["exact_queries"] / args.steps, 2),
@@ -171,6 +172,13 @@ def main():
     if stage_ms:
         line["config"]["stage_ms_per_step"] = {k_: round(v / args.steps, 4) for k_, v in stage_ms.items()}
 
+    # ---- quality of the answers (not part of the metric): exact-rank recall of a 512-query sample, by GPU brute force
+    if world == 1 and rank == 0:
+        qs = min(512, Q)
+        g_ids, _, _ = ix.query(batches[0][:qs].contiguous())
+        rk = A.recall_ranks(points, batches[0][:qs].contiguous(), g_ids)
+        line["config"]["recall_sample"] = {kk: round(v, 4) for kk, v in A.recall_summary(rk, k).items()}
+        line["config"]["recall_sample"]["queries"] = qs
     # ---- CPU baseline + full-size parity sample (rank 0, single GPU only)
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args, ix, points, batches[0], libc)

@@ -101,6 +101,14 @@ void annhip_exact_select(annhip_index *ix, int stage, size_t nq, uint32_t *ids_d
 /* u32 -> size_t on the device */
 void annhip_widen_ids(annhip_index *ix, size_t count, const uint32_t *in_dev, size_t *out_dev);
 
+/* ---- recall scoring (counterpart of /root/reference/test_correctness.c:169-262) --------------- */
+/* ranks_dev[q][j] (u64) = number of the n points strictly closer to query q than its j-th guessed neighbour, by one
+ * tiled brute-force pass with the exact distance arithmetic of the query path.  points_dev holds ALL n rows;
+ * guess_dev is size_t[ycnt][k] as query()/precomp() return it; self != 0 skips point q for query q (scoring the
+ * graph precomp returns).  Synchronous. */
+void annhip_recall_ranks(size_t n, size_t d, size_t k, const ftype *points_dev, size_t ycnt, const ftype *y_dev,
+                         const size_t *guess_dev, int self, unsigned long long *ranks_dev);
+
 /* ---- measurement ---------------------------------------------------------------------------------- */
 /* profile != 0: bracket every stage1 launch with HIP events on the index's stream. */
 void annhip_profile(annhip_index *ix, int profile);
