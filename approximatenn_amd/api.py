@@ -245,14 +245,25 @@ class Index:
     def set_stream(self, stream_ptr):
         self.lib.annhip_index_set_stream(self.h, stream_ptr)
 
-    def query(self, y, alias=False, mode=0, out_ids=None, out_dists=None):
-        """annhip_query: y torch tensor [Q,d] on the device -> (ids int64 [Q,k], sq dists [Q,k], n_exact)."""
+    def workspace(self):
+        """annhip_workspace_create: scratch for one in-flight batch (pass to query(ws=..., stream=...))."""
+        ws = self.lib.annhip_workspace_create(self.h)
+        self._workspaces = getattr(self, "_workspaces", []) + [ws]
+        return ws
+
+    def query(self, y, alias=False, mode=0, out_ids=None, out_dists=None, ws=None, stream=None):
+        """annhip_query / annhip_query_on: y torch tensor [Q,d] on the device -> (ids int64 [Q,k], sq dists [Q,k], n_exact).
+        ws + stream (a torch.cuda.Stream): run this batch on its own workspace and stream so that it can overlap others."""
         import torch
         assert y.is_cuda and y.is_contiguous() and y.dtype == self._torch_ft(self.prec) and y.shape[1] == self.d
         Q = y.shape[0]
         ids = out_ids if out_ids is not None else torch.empty((Q, self.k), dtype=torch.int64, device=y.device)
         dists = out_dists if out_dists is not None else torch.empty((Q, self.k), dtype=y.dtype, device=y.device)
-        nex = self.lib.annhip_query(self.h, Q, y.data_ptr(), int(alias), mode, ids.data_ptr(), dists.data_ptr())
+        if ws is None and stream is None:
+            nex = self.lib.annhip_query(self.h, Q, y.data_ptr(), int(alias), mode, ids.data_ptr(), dists.data_ptr())
+        else:
+            nex = self.lib.annhip_query_on(self.h, ws, stream.cuda_stream if stream is not None else None, Q, y.data_ptr(),
+                                           int(alias), mode, ids.data_ptr(), dists.data_ptr())
         return ids, dists, nex
 
     def profile(self, on=True):
@@ -271,6 +282,9 @@ class Index:
 
     def close(self):
         if self.h:
+            for ws in getattr(self, "_workspaces", []):
+                self.lib.annhip_workspace_destroy(ws)
+            self._workspaces = []
             self.lib.annhip_index_destroy(self.h)
             self.h = None
 

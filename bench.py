@@ -43,6 +43,13 @@ def parse():
     ap.add_argument("--tries", type=int, default=10)
     ap.add_argument("--queries", dest="q", type=int, default=10_000, help="queries per GPU per step")
     ap.add_argument("--seed", type=int, default=12345)
+    ap.add_argument("--streams", type=int, default=1,
+                    help="single GPU: 1 = strictly serial steps (default; per-launch kernel times are meaningful); "
+                         "N > 1 = independent batches alternate over N HIP streams/workspaces, so the latency-bound tail "
+                         "of one step and the workgroup tail of its gather hide under the next step's gather")
+    ap.add_argument("--no-overlap-extra", action="store_true",
+                    help="skip the extra 2-stream throughput measurement reported under 'overlap'")
+    ap.add_argument("--dtype", choices=["f32", "f64"], default="f32", help="f64 = the reference's stock double build")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
@@ -72,13 +79,15 @@ def main():
         dist.init_process_group(backend=backend)
 
     n, d, k, T = args.n, args.d, args.k, args.tries
+    tdt = torch.float32 if args.dtype == "f32" else torch.float64
+    esz = 4 if args.dtype == "f32" else 8
     Q = args.q * world  # weak scaling: the batch grows with the number of shards
     libc = ctypes.CDLL("libc.so.6")
 
     # ---- synthetic data + index (identical on every rank: same seeds, deterministic build)
     gen = torch.Generator(device=device)
     gen.manual_seed(args.seed)
-    points = torch.randn((n, d), device=device, dtype=torch.float32, generator=gen)
+    points = torch.randn((n, d), device=device, dtype=tdt, generator=gen)
     libc.srandom(args.seed)
     torch.cuda.synchronize()
     t0 = time.time()
@@ -86,7 +95,7 @@ def main():
     torch.cuda.synchronize()
     precomp_s = time.time() - t0
     ix.set_stream(torch.cuda.current_stream().cuda_stream)
-    batches = [torch.randn((Q, d), device=device, dtype=torch.float32, generator=gen)
+    batches = [torch.randn((Q, d), device=device, dtype=tdt, generator=gen)
                for _ in range(args.warmup + args.steps)]
 
     if world > 1:
@@ -106,9 +115,19 @@ def main():
             runner = ShardedQuery(ix, dist, fast=False)
         step = lambda y: runner.query(y)
     else:
-        out_ids = torch.empty((Q, k), dtype=torch.int64, device=device)
-        out_d = torch.empty((Q, k), dtype=torch.float32, device=device)
-        step = lambda y: ix.query(y, out_ids=out_ids, out_dists=out_d)
+        ns = max(1, args.streams)
+        out_ids = [torch.empty((Q, k), dtype=torch.int64, device=device) for _ in range(ns)]
+        out_d = [torch.empty((Q, k), dtype=tdt, device=device) for _ in range(ns)]
+        if ns == 1:
+            step = lambda y: ix.query(y, out_ids=out_ids[0], out_dists=out_d[0])
+        else:
+            lanes = [(ix.workspace(), torch.cuda.Stream(device=device)) for _ in range(ns)]
+            counter = [0]
+
+            def step(y):
+                j = counter[0] % ns
+                counter[0] += 1
+                ix.query(y, out_ids=out_ids[j], out_dists=out_d[j], ws=lanes[j][0], stream=lanes[j][1])
 
     def barrier():
         if world > 1:
@@ -140,10 +159,10 @@ def main():
     launches = max(st["s1_launches"], 1.0)
     v1 = st["s1_rows"] / max(st["queries"], 1.0)            # rows THIS device gathered per query
     kern_ms = st["s1_ms"] / launches
-    bytes_per_query = v1 * d * 4 + ix.P1 * 4 + d * 4 + T * 4 + (k + 1) * 8
+    bytes_per_query = v1 * d * esz + ix.P1 * 4 + d * esz + T * 4 + (k + 1) * (esz + 4)
     bytes_per_launch = bytes_per_query * Q
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": "stage1_select_kernel<128>", "achieved": round(achieved, 1),
+    roofline = {"bound": "hbm", "kernel": "stage1_select_kernel<%d>" % d, "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
                 "rows_gathered_per_query": round(v1, 1)}
@@ -151,7 +170,7 @@ def main():
     # PMC traffic cannot be read in-process; for the default workload it comes from the committed rocprofv3 passes
     try:
         tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        if world == 1 and (n, d, k, T, Q) == (10_000_000, 128, 10, 10, 10_000):
+        if world == 1 and (n, d, k, T, Q, args.dtype) == (10_000_000, 128, 10, 10, 10_000, "f32"):
             roofline["traffic"] = tr["traffic_bytes_per_launch"]
             roofline["traffic_source"] = tr["source"]
     except (OSError, ValueError, KeyError):
@@ -161,10 +180,10 @@ def main():
     line = {"metric": "queries/sec, N=10M d=128 k=10 Q=10k float (query(): hash + candidate gather + L2 + top-k + refine)",
             "value": round(value, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "%sN=%d d=%d k=%d tries=%d Q=%d/step float, randn points+queries"
-                       % ("cfg3: " if (n, d, k, args.q) == (10_000_000, 128, 10, 10_000) else "", n, d, k, T, Q),
-                       "points_sharding": "rows/%d" % world, "d_short": ix.d_short, "L1": ix.L1, "P1": ix.P1,
+                       % ("cfg3: " if (n, d, k, args.q, args.dtype) == (10_000_000, 128, 10, 10_000, "f32") else "", n, d, k, T, Q),
+                       "points_sharding": "rows/%d" % world, "streams": (max(1, args.streams) if world == 1 else 1), "d_short": ix.d_short, "L1": ix.L1, "P1": ix.P1,
                        "L2": ix.L2, "P2": ix.P2, "sum_par_maxes": ix.sum_pm, "precomp_s": round(precomp_s, 2),
                        "exact_path_queries_per_step": round(st["exact_queries"] / args.steps, 2),
                        "host_submit_ms_per_step": round(submit_s / args.steps * 1e3, 4)},
@@ -172,6 +191,22 @@ def main():
     if stage_ms:
         line["config"]["stage_ms_per_step"] = {k_: round(v / args.steps, 4) for k_, v in stage_ms.items()}
 
+    # ---- extra: the same K steps with consecutive batches overlapped on two streams (annhip_query_on); reported
+    #      beside `value`, never instead of it: per-launch kernel times are not meaningful while gathers overlap
+    if world == 1 and rank == 0 and max(1, args.streams) == 1 and not args.no_overlap_extra:
+        lanes = [(ix.workspace(), torch.cuda.Stream(device=device)) for _ in range(2)]
+        o_ids = [torch.empty((Q, k), dtype=torch.int64, device=device) for _ in range(2)]
+        o_d = [torch.empty((Q, k), dtype=tdt, device=device) for _ in range(2)]
+        for i in range(args.warmup + args.steps):
+            if i == args.warmup:
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+            ix.query(batches[i], out_ids=o_ids[i % 2], out_dists=o_d[i % 2], ws=lanes[i % 2][0], stream=lanes[i % 2][1])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        line["overlap"] = {"streams": 2, "value": round(Q * args.steps / dt, 1), "unit": "queries/s",
+                           "ms_per_step": round(dt / args.steps * 1e3, 4),
+                           "note": "consecutive batches on 2 HIP streams/workspaces; same work, same results"}
     # ---- quality of the answers (not part of the metric): exact-rank recall of a 512-query sample, by GPU brute force
     if world == 1 and rank == 0:
         qs = min(512, Q)
@@ -199,8 +234,8 @@ def cpu_baseline(args, ix, points, y_dev, libc):
     arrays = save.to_dict()
     save.free()
     host_pts = points.cpu().numpy()
-    orc = O.CpuBackend("f32", "oracle")
-    hs = O.HostSave(arrays, "f32")
+    orc = O.CpuBackend(args.dtype, "oracle")
+    hs = O.HostSave(arrays, args.dtype)
     qs = 64
     y = y_dev[:qs].cpu().numpy()
     t0 = time.perf_counter()
@@ -214,7 +249,7 @@ def cpu_baseline(args, ix, points, y_dev, libc):
     g_ids, g_d, _ = ix.query(y_dev[:qs].contiguous())
     torch.cuda.synchronize()
     ids_equal = bool(np.array_equal(g_ids.cpu().numpy().astype(np.uint64), o_ids))
-    d_equal = bool(np.array_equal(g_d.cpu().numpy().view(np.uint32), o_d.view(np.uint32)))
+    d_equal = bool(np.array_equal(g_d.cpu().numpy().view(np.uint8), o_d.view(np.uint8)))
     return {"value": round(qs / cpu_s, 2), "unit": "queries/s", "cores": 1, "kind": "port",
             "sample": "%d-query batch of the same workload on the GPU-built index (oracle, 1 thread, %.1f s)" % (qs, cpu_s),
             "host_cores_available": os.cpu_count(),

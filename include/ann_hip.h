@@ -64,6 +64,17 @@ annhip_index *annhip_precomp_index(size_t n, size_t k, size_t d, const ftype *po
 long annhip_query(annhip_index *ix, size_t ycnt, const ftype *y_dev, int alias, int mode,
                   size_t *ids_dev, ftype *dists_dev);
 
+/* ---- overlapping independent batches ---------------------------------------------------------- */
+/* annhip_query keeps its scratch in the index, so calls on one index are serial.  A caller that has several
+ * independent batches gives each in-flight batch its own workspace and HIP stream: the small latency-bound stages of
+ * batch i (hash, finalize, stage 2) then run underneath the HBM-bound stage-1 gather of batch i+1.
+ * annhip_query_on = annhip_query with explicit workspace (NULL = the index's) and stream (a hipStream_t). */
+typedef struct annhip_workspace annhip_workspace;
+annhip_workspace *annhip_workspace_create(annhip_index *ix);
+void annhip_workspace_destroy(annhip_workspace *ws);
+long annhip_query_on(annhip_index *ix, annhip_workspace *ws, void *hip_stream, size_t ycnt, const ftype *y_dev,
+                     int alias, int mode, size_t *ids_dev, ftype *dists_dev);
+
 /* ---- staged query, for point-sharded multi-GPU hosts -------------------------------------------- */
 /* 1. hash codes of the whole batch: codes_dev u32[ycnt*tries], layout [q*tries+t] (alg.c:462-492).     */
 void annhip_codes(annhip_index *ix, size_t ycnt, const ftype *y_dev, uint32_t *codes_dev);

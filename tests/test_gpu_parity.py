@@ -125,3 +125,24 @@ def test_precomp_is_first_gpu_call_in_a_fresh_process():
     out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "smoke ok" in out.stdout
+
+
+def test_overlapped_batches_on_two_streams_match():
+    """annhip_query_on: independent batches on their own workspace + stream give the serial answers."""
+    import torch
+    g = load_golden("pow2_d128_f32")
+    save = A.Save.from_dict("f32", g["save"])
+    ix = A.Index.from_save(save, torch.from_numpy(g["points"]).cuda())
+    y = torch.from_numpy(g["y"]).cuda()
+    ys = [y, y.flip(0).contiguous(), y[:17].contiguous(), y]
+    want = [ix.query(t)[:2] for t in ys]
+    torch.cuda.synchronize()
+    lanes = [(ix.workspace(), torch.cuda.Stream()) for _ in range(2)]
+    got = []
+    for rep in range(3):
+        got = [ix.query(t, ws=lanes[i % 2][0], stream=lanes[i % 2][1])[:2] for i, t in enumerate(ys)]
+    torch.cuda.synchronize()
+    for (wi, wd), (gi, gd) in zip(want, got):
+        assert torch.equal(wi, gi) and torch.equal(wd.view(torch.int32), gd.view(torch.int32))
+    _check(got[0][0].cpu().numpy().astype(np.uint64), got[0][1].cpu().numpy(), g["query_ids"], g["query_dists"], "overlapped")
+    ix.close()
