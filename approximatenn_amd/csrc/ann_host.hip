@@ -614,7 +614,6 @@ static long finalize_and_fallback(annhip_index *ix, const QParams &P, size_t Q, 
                        P.P1, cand_d, cand_i, nvt, top_i, top_d, ostride, ooff, fl, d_fcount, exact_total);
     HIPCHECK(hipGetLastError());
     if (device_driven && Q <= chunk) {
-      if (getenv("ANN_HIP_DEBUG_SKIP_FALLBACK")) return -1;  // timing experiments only (wrong results on ties)
       u32 *ids = (u32 *)xids.need(sizeof(u32) * Q * P.Lc1);
       FT *dist = (FT *)xd.need(sizeof(FT) * Q * P.Lc1);
       launch_rows<MODE_TABLE>(P, Q, y, alias, codes, fl, 0, Q, P.Lc1, NULL, NULL, ids, dist, rows_done, s, d_fcount);
