@@ -537,6 +537,37 @@ static void launch_stage1(annhip_index *ix, const QParams &P, size_t Q, const FT
   if (ix) ix->s1_launches += 1;
 }
 
+template <int DD>
+static void launch_bucket_d(const QParams &P, size_t nbuckets, int W, int K1, int cap, u32 list_cap, size_t smem, FT *cand_d,
+                            u32 *cand_i, u32 *nvt, u32 *nvo, hipStream_t s) {
+  if constexpr (DD > 0) {
+    allow_lds(stage1_bucket_kernel<DD>, smem);
+    hipLaunchKernelGGL(stage1_bucket_kernel<DD>, dim3((unsigned)nbuckets), dim3(64 * W), smem, s, P, K1, cap, list_cap, cand_d,
+                       cand_i, nvt, nvo);
+  }
+}
+
+// bucket-centric stage 1 of precomp: returns false when the shape does not fit (caller uses the per-point kernel)
+static bool launch_stage1_bucket(const QParams &P, const TryInfo &one, size_t nbuckets, FT *cand_d, u32 *cand_i, u32 *nvt,
+                                 u32 *nvo, hipStream_t s) {
+  if (!d_is_fast(P.d) || getenv("ANN_HIP_POINT_PRECOMP")) return false;
+  const int K1 = P.k + 1, W = 4;
+  int cap = K1 + 2 * 16;  // room for one pass of up to RPW = 16 keys after a shrink
+  cap = (cap + 7) & ~7;
+  const size_t tile = sizeof(VT) * (size_t)ANN_BK_TILE_ROWS * (P.d / ANN_VEC + 1);
+  if (P.ds + 1 > ANN_BK_MAX_RUNS) return false;
+  const u32 list_cap = std::min<u32>(P.P1, (u32)(P.ds + 1) * one.pm);
+  const size_t smem = tile + sizeof(Key) * (size_t)one.pm * cap + sizeof(Key) * (size_t)W * K1 + sizeof(Key) * (size_t)one.pm +
+                      sizeof(u32) * (size_t)list_cap + sizeof(int) * (size_t)one.pm + sizeof(u32) * (ANN_BK_MAX_RUNS + 1) + 16;
+  if (smem > 80 * 1024) return false;  // keep two workgroups per CU
+  if ((u32)P.k > P.P1) return false;
+#define CALL(DD) launch_bucket_d<DD>(P, nbuckets, W, K1, cap, list_cap, smem, cand_d, cand_i, nvt, nvo, s)
+  ANN_DISPATCH_D(P.d, CALL);
+#undef CALL
+  HIPCHECK(hipGetLastError());
+  return true;
+}
+
 static size_t rows_lds_bytes(const QParams &P, u32 chunk) {
   size_t b = 2 * sizeof(u32) * (size_t)chunk + sizeof(TryInfo) * (size_t)P.T + sizeof(u32) * (size_t)P.T + 16;
   b = (b + 15) & ~(size_t)15;
@@ -1111,7 +1142,8 @@ extern "C" annhip_index *annhip_precomp_index(size_t n, size_t k, size_t d, cons
       ci = (u32 *)cand_i.need(sizeof(u32) * n * (k + 1));
       nv = (u32 *)nvt.need(sizeof(u32) * n);
       u32 *no = (u32 *)nvo.need(sizeof(u32) * n);
-      launch_stage1(NULL, P, n, pts, 1, codes[t], cd, ci, nv, no, s, std::vector<TryInfo>(1, one), !getenv("ANN_HIP_SLOT_SCAN"));
+      if (!launch_stage1_bucket(P, one, nb, cd, ci, nv, no, s))
+        launch_stage1(NULL, P, n, pts, 1, codes[t], cd, ci, nv, no, s, std::vector<TryInfo>(1, one), !getenv("ANN_HIP_SLOT_SCAN"));
     }
     finalize_and_fallback(NULL, P, n, pts, 1, codes[t], mode, cd, ci, nv, merged_i, merged_d, (int)W, (int)(t * k),
                           flist, xids, xd, ix->ws.d_fcount, NULL, NULL, false, s);

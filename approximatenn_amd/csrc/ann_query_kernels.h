@@ -425,6 +425,129 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
   }
 }
 
+// ---------------------------------------------------------------------------------- stage1_bucket
+// precomp's second_half (alg.c:245-290), bucket-centric.  Every point of a bucket has the same hash code, hence the
+// same candidate row (its own bucket + the d_short Hamming-1 buckets, compute.cl:238-246): the per-point kernel
+// re-gathers those ~200 rows for each of the ~10 members.  Here one workgroup owns one bucket: it stages the
+// candidate rows in LDS tile by tile (read once from HBM) and every wave scores its share of the members against the
+// tile, each member keeping its own running selection in LDS.  Same distances, same selection, same outputs as
+// stage1_select with alias = 1 (self excluded); nv_tot is exact here (valid slots minus the member itself).
+// Host-side conditions (else the per-point kernel is used): power-of-two d, pm members' selection state + one tile
+// fit LDS.
+#define ANN_BK_TILE_ROWS 64
+#define ANN_BK_MAX_RUNS 64
+template <int D>
+__global__ __launch_bounds__(256) void stage1_bucket_kernel(QParams P, int K1, int cap, u32 list_cap,
+                                                            FT *__restrict__ cand_dist, u32 *__restrict__ cand_id,
+                                                            u32 *__restrict__ nv_tot, u32 *__restrict__ nv_own) {
+  typedef RowLay<D> L;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = lane_id(), w = threadIdx.x >> 6, W = blockDim.x >> 6;
+  const TryInfo tr = P.tries[0];  // one-try view
+  const u32 b = blockIdx.x, pm = tr.pm;
+  const u32 members = tr.seg[b].y;  // valid ids of this bucket (in precomp the owned range is everything)
+  if (members == 0) return;
+  constexpr int ROWV = D / ANN_VEC + 1;  // tile row stride in 16-byte units (+1: spreads rows over LDS banks)
+  unsigned char *sp = smem;
+  VT *tile = reinterpret_cast<VT *>(sp);                 sp += sizeof(VT) * (size_t)ANN_BK_TILE_ROWS * ROWV;
+  Key *kbuf_all = reinterpret_cast<Key *>(sp);           sp += sizeof(Key) * (size_t)pm * cap;
+  Key *kout_all = reinterpret_cast<Key *>(sp);           sp += sizeof(Key) * (size_t)W * K1;
+  Key *tau_all = reinterpret_cast<Key *>(sp);            sp += sizeof(Key) * (size_t)pm;
+  u32 *clist = reinterpret_cast<u32 *>(sp);              sp += sizeof(u32) * (size_t)list_cap;  // candidate ids, slot order
+  int *kcnt_all = reinterpret_cast<int *>(sp);           sp += sizeof(int) * (size_t)pm;
+  u32 *roff = reinterpret_cast<u32 *>(sp);               sp += sizeof(u32) * (ANN_BK_MAX_RUNS + 1);
+  const u32 *mem_ids = tr.tab + (size_t)b * pm;  // members, descending ids
+  const u32 ds1 = (u32)P.ds + 1u;
+  for (u32 m = threadIdx.x; m < members; m += blockDim.x) {
+    kcnt_all[m] = 0;
+    tau_all[m] = key_max();
+  }
+  // valid ids of every run below P1 (the first seg.y entries of the neighbour bucket's row): counts, then offsets
+  if (threadIdx.x < ds1) {
+    const u32 yy = threadIdx.x, start = yy * pm;
+    const u32 nb = b ^ (yy ? 1u << (yy - 1) : 0u);
+    roff[yy + 1] = start < P.P1 ? min(tr.seg[nb].y, min(pm, P.P1 - start)) : 0u;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    roff[0] = 0;
+    for (u32 yy = 0; yy < ds1; yy++) roff[yy + 1] += roff[yy];
+  }
+  __syncthreads();
+  const u32 total = roff[ds1];  // valid slots below P1: the same for every member
+  for (u32 e = threadIdx.x; e < ds1 * pm; e += blockDim.x) {
+    const u32 yy = e / pm, z = e - yy * pm;
+    if (z < roff[yy + 1] - roff[yy]) {
+      const u32 nb = b ^ (yy ? 1u << (yy - 1) : 0u);
+      clist[roff[yy] + z] = tr.tab[(size_t)nb * pm + z];
+    }
+  }
+  __syncthreads();
+
+  const int p = lane % L::LPR, g = lane / L::LPR;
+  for (u32 r0 = 0; r0 < total; r0 += ANN_BK_TILE_ROWS) {
+    const u32 rows = min((u32)ANN_BK_TILE_ROWS, total - r0);
+    if (r0) __syncthreads();  // previous tile fully consumed
+    // stage `rows` candidate rows: LPR lanes per row, whole 128-byte pieces per load instruction
+    for (u32 r = (u32)(threadIdx.x / L::LPR); r < rows; r += blockDim.x / L::LPR) {
+      const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)clist[r0 + r] * D) + p;
+#pragma unroll
+      for (int c = 0; c < L::C; c++) tile[(size_t)r * ROWV + p + c * L::LPR] = load_row_chunk<true>(rp + c * L::LPR);
+    }
+    __syncthreads();
+    // every wave scores its members against the tile
+    for (u32 m = w; m < members; m += W) {
+      const u32 x = mem_ids[m];
+      VT a[L::C];
+      const VT *yp = reinterpret_cast<const VT *>(P.points + (size_t)x * D) + p;
+#pragma unroll
+      for (int c = 0; c < L::C; c++) a[c] = yp[c * L::LPR];
+      SelState S;
+      S.kbuf = kbuf_all + (size_t)m * cap, S.kout = kout_all + (size_t)w * K1;
+      S.kcnt = kcnt_all[m], S.K1 = K1, S.cap = cap, S.tau = tau_all[m];
+      for (u32 base = 0; base < rows; base += L::RPW) {
+        const u32 r = base + g;
+        const bool inb = r < rows;
+        const u32 id = clist[r0 + (inb ? r : base)];
+        VT bv[L::C];
+        const VT *tp = tile + (size_t)(inb ? r : base) * ROWV + p;
+#pragma unroll
+        for (int c = 0; c < L::C; c++) bv[c] = tp[c * L::LPR];
+        const FT dist = row_reduce<D, ROW_SQDIFF>(a, bv);
+        const Key key = key_make(dist, id);
+        const bool pass = inb && id != x && p == 0 && key_less(key, S.tau);
+        const u64 mm = __ballot(pass);
+        if (mm) {
+          if (pass) S.kbuf[S.kcnt + mask_rank(mm)] = key;
+          S.kcnt += __popcll(mm);
+          if (S.kcnt + L::RPW > S.cap) sel_shrink(S);
+        }
+      }
+      wave_lds_sync();
+      if (lane == 0) {
+        kcnt_all[m] = S.kcnt;
+        tau_all[m] = S.tau;
+      }
+    }
+  }
+  __syncthreads();
+  // final selection per member
+  for (u32 m = w; m < members; m += W) {
+    const u32 x = mem_ids[m];
+    Key *kout = kout_all + (size_t)w * K1;
+    const int got = wave_select_smallest(kbuf_all + (size_t)m * cap, kcnt_all[m], K1, kout);
+    for (int i = lane; i < K1; i += ANN_WAVE) {
+      cand_dist[(size_t)x * K1 + i] = i < got ? key_dist(kout[i]) : ft_inf();
+      cand_id[(size_t)x * K1 + i] = i < got ? key_id(kout[i]) : ANN_ID_NONE;
+    }
+    if (lane == 0) {
+      nv_tot[x] = total - 1u;  // the member itself sits in its own bucket's run, below P1
+      nv_own[x] = total - 1u;
+    }
+    wave_lds_sync();
+  }
+}
+
 // -------------------------------------------------------------------------------------- finalize1
 // Decide, per query, whether the K1 = k+1 smallest distinct keys determine the reference's stage-1
 // output.  They do when (a) at least k of them exist and are finite, (b) no two of them share a distance
