@@ -203,6 +203,87 @@ __device__ __forceinline__ FT row_reduce(const VT (&a)[RowLay<D>::C], const VT (
   return e[0][0];
 }
 
+// ------------------------------------------------------------------ row layout for d = oc * 2^a chunks
+// Any d that is a multiple of the 16-byte chunk (VEC elements): write d/VEC = oc * C with C = 2^a (a as large as
+// possible, C <= 8) and oc odd.  `oc` lanes share a row; lane position p holds chunks p, p+oc, ..., p+(C-1)oc, i.e.
+// elements z = VEC*(p + oc*c) + j.  The top a levels of the tree pair z with z + s/2 where s/2 is a multiple of
+// oc*VEC -> chunk c with c + C/2, ... : in-lane, exactly as in RowLay.  What remains are m = oc*VEC partial sums,
+// element VEC*p + j in lane p: the literal tree on those (odd levels included) runs across the lanes with
+// shuffles whose lane offset and source register are wave-uniform per (level, j).  Result valid in lane position 0.
+// Kernels encode this layout as a NEGATIVE template argument D = -C; oc comes at run time (P.d / (VEC*C)).
+template <int D, bool POW2 = (D > 0)>
+struct RowChunks;
+template <int D>
+struct RowChunks<D, true> {
+  static constexpr int C = RowLay<D>::C;
+};
+template <int D>
+struct RowChunks<D, false> {
+  static constexpr int C = D < 0 ? -D : 1;
+};
+
+// v[r] of lane `src`, r wave-uniform.  Written as a uniform switch (one shuffle per case): a select chain over the
+// registers is turned by the compiler into a store/load through scratch memory.
+__device__ __forceinline__ FT shfl_reg(const FT (&v)[ANN_VEC], int r, int src) {
+  FT o;
+  switch (__builtin_amdgcn_readfirstlane(r)) {
+    case 0: o = __shfl(v[0], src); break;
+    case 1: o = __shfl(v[1], src); break;
+#if ANN_VEC > 2
+    case 2: o = __shfl(v[2], src); break;
+    default: o = __shfl(v[3], src); break;
+#else
+    default: o = __shfl(v[1], src); break;
+#endif
+  }
+  return o;
+}
+
+template <int C, int MODE>
+__device__ __forceinline__ FT row_reduce_oc(const VT (&a)[C], const VT (&b)[C], int oc, int p) {
+  FT e[C][ANN_VEC];
+#pragma unroll
+  for (int c = 0; c < C; c++) {
+    const FT *pa = reinterpret_cast<const FT *>(&a[c]);
+    const FT *pb = reinterpret_cast<const FT *>(&b[c]);
+#pragma unroll
+    for (int j = 0; j < ANN_VEC; j++) {
+      if (MODE == ROW_SQDIFF) {
+        FT df = pa[j] - pb[j];
+        e[c][j] = df * df;
+      } else {
+        e[c][j] = pa[j] * pb[j];
+      }
+    }
+  }
+  const FT zero = 0;
+#pragma unroll
+  for (int h = C / 2; h >= 1; h >>= 1)
+#pragma unroll
+    for (int c = 0; c < h; c++)
+#pragma unroll
+      for (int j = 0; j < ANN_VEC; j++)
+        e[c][j] = (MODE == ROW_PRODUCT) ? e[c][j] + (e[c + h][j] + zero) : e[c][j] + e[c + h][j];
+  // tail: literal tree (compute.cl:160-167) over m = oc*VEC values, value z = VEC*p + j lives in e[0][j] of lane p
+  const int lane = lane_id();
+  for (int s = oc * ANN_VEC; s >> 1; s >>= 1) {
+    const int h = s >> 1;
+    FT g = zero;
+    if (s & 1) {  // g = m[s-1], added into z == 0 only; every lane takes part in the shuffle
+      const int zz = s - 1;
+      g = shfl_reg(e[0], zz % ANN_VEC, lane - p + zz / ANN_VEC);
+    }
+#pragma unroll
+    for (int j = 0; j < ANN_VEC; j++) {
+      const int hh = j + h;  // partner of z = VEC*p + j is z + h = VEC*(p + hh/VEC) + hh%VEC
+      const FT o = shfl_reg(e[0], hh % ANN_VEC, lane + hh / ANN_VEC);
+      const int z = ANN_VEC * p + j;
+      if (z < h) e[0][j] = e[0][j] + (o + ((z == 0) ? g : zero));  // values >= h are only read at this level
+    }
+  }
+  return e[0][0];
+}
+
 // Any d: the whole wave works on one row, staging the d terms in LDS scratch m[d] and running the
 // in-place tree literally (odd s term included).  a = left operand (LDS or global), b = row (global).
 // Returns the sum in every lane.

@@ -382,39 +382,45 @@ extern "C" void annhip_index_export(const annhip_index *ix, save_t *save) {
 }
 
 // ----------------------------------------------------------------------------- launchers
-// power-of-two row lengths with a register layout; everything else takes the generic (D = 0) kernels
-#ifdef USE_FLOAT
-#define ANN_DISPATCH_D(dval, CALL) \
-  switch (dval) {                  \
-    case 16: CALL(16); break;      \
-    case 32: CALL(32); break;      \
-    case 64: CALL(64); break;      \
-    case 128: CALL(128); break;    \
-    case 256: CALL(256); break;    \
-    case 512: CALL(512); break;    \
-    case 1024: CALL(1024); break;  \
-    default: CALL(0); break;       \
+// Row layouts (ann_device.h): D > 0 = power of two (RowLay<D>); D = -C = d/VEC is oc * C chunks, C = 2^a <= 8, oc <= 64
+// lanes per row (row_reduce_oc; e.g. the reference drivers' default d = 80); D = 0 = any d (literal tree through LDS).
+static int layout_code(size_t d, bool allow_oc = true) {
+  if (d >= 16 && (d & (d - 1)) == 0 && d <= (sizeof(FT) == 4 ? 1024u : 512u)) return (int)d;
+  if (allow_oc && d % ANN_VEC == 0) {
+    size_t nc = d / ANN_VEC, C = 1;
+    while (C < 8 && nc % (2 * C) == 0) C *= 2;
+    const size_t oc = nc / C;
+    if (oc >= 2 && oc <= 64) return -(int)C;
   }
-#else
-#define ANN_DISPATCH_D(dval, CALL) \
-  switch (dval) {                  \
-    case 16: CALL(16); break;      \
-    case 32: CALL(32); break;      \
-    case 64: CALL(64); break;      \
-    case 128: CALL(128); break;    \
-    case 256: CALL(256); break;    \
-    case 512: CALL(512); break;    \
-    default: CALL(0); break;       \
-  }
-#endif
-
-static bool d_is_fast(size_t d) {
-  int probe = -1;
-#define PROBE(DD) probe = DD
-  ANN_DISPATCH_D((int)d, PROBE);
-#undef PROBE
-  return probe > 0;
+  return 0;
 }
+#define ANN_DISPATCH_CODE(code, CALL) \
+  switch (code) {                     \
+    case 16: CALL(16); break;         \
+    case 32: CALL(32); break;         \
+    case 64: CALL(64); break;         \
+    case 128: CALL(128); break;       \
+    case 256: CALL(256); break;       \
+    case 512: CALL(512); break;       \
+    ANN_CASE_1024(CALL)               \
+    case -1: CALL(-1); break;         \
+    case -2: CALL(-2); break;         \
+    case -4: CALL(-4); break;         \
+    case -8: CALL(-8); break;         \
+    default: CALL(0); break;          \
+  }
+#ifdef USE_FLOAT
+#define ANN_CASE_1024(CALL) case 1024: CALL(1024); break;
+#else
+#define ANN_CASE_1024(CALL)
+#endif
+// kernels that know all three layouts (codes, stage 1, rows)
+#define ANN_DISPATCH_D(dval, CALL) ANN_DISPATCH_CODE(layout_code((size_t)(dval)), CALL)
+// kernels with the power-of-two and the generic layout only (bucket-centric precomp, recall)
+#define ANN_DISPATCH_D2(dval, CALL) ANN_DISPATCH_CODE(layout_code((size_t)(dval), false), CALL)
+
+static bool d_is_fast(size_t d) { return layout_code(d, false) > 0; }   // power-of-two register layout
+static bool d_needs_lds_row(size_t d) { return layout_code(d) == 0; }    // literal tree through LDS
 
 template <typename K>
 static void allow_lds(K kernel, size_t bytes) {
@@ -444,9 +450,16 @@ static void launch_codes(const QParams &P, size_t Qhash, const FT *y, u32 *codes
 #undef CALL
   } else {
     const unsigned grid = (unsigned)((items + wpb - 1) / wpb);
-    const size_t smem = sizeof(FT) * wpb * 2 * (size_t)P.d;
-    allow_lds(codes_kernel<0>, smem);
-    hipLaunchKernelGGL(codes_kernel<0>, dim3(grid), dim3(64 * wpb), smem, s, P, (int)Q, y, codes);
+    const size_t smem = d_needs_lds_row(P.d) ? sizeof(FT) * wpb * 2 * (size_t)P.d : 0;
+#define CALL(DD)                                                                                      \
+  do {                                                                                                \
+    if (DD <= 0) {                                                                                    \
+      allow_lds(codes_kernel<(DD <= 0 ? DD : 0)>, smem);                                              \
+      hipLaunchKernelGGL(codes_kernel<(DD <= 0 ? DD : 0)>, dim3(grid), dim3(64 * wpb), smem, s, P, (int)Q, y, codes); \
+    }                                                                                                 \
+  } while (0)
+    ANN_DISPATCH_D(P.d, CALL);
+#undef CALL
   }
   HIPCHECK(hipGetLastError());
 }
@@ -473,7 +486,7 @@ static size_t stage1_lds_bytes(const QParams &P, int W, int K1, int cap) {
              sizeof(u32 *) * (size_t)W * ANN_WAVE + sizeof(u32) * (size_t)W * ANN_S1_CHUNK +
              sizeof(u32) * (size_t)W * ANN_WAVE + sizeof(u32) * (size_t)P.T + sizeof(int) * (size_t)W + sizeof(u32) * 2;
   b = (b + 15) & ~(size_t)15;
-  if (!d_is_fast(P.d)) b += sizeof(FT) * (size_t)P.d * (1 + W);
+  if (d_needs_lds_row(P.d)) b += sizeof(FT) * (size_t)P.d * (1 + W);
   return b;
 }
 
@@ -562,7 +575,7 @@ static bool launch_stage1_bucket(const QParams &P, const TryInfo &one, size_t nb
   if (smem > 80 * 1024) return false;  // keep two workgroups per CU
   if ((u32)P.k > P.P1) return false;
 #define CALL(DD) launch_bucket_d<DD>(P, nbuckets, W, K1, cap, list_cap, smem, cand_d, cand_i, nvt, nvo, s)
-  ANN_DISPATCH_D(P.d, CALL);
+  ANN_DISPATCH_D2(P.d, CALL);
 #undef CALL
   HIPCHECK(hipGetLastError());
   return true;
@@ -571,7 +584,7 @@ static bool launch_stage1_bucket(const QParams &P, const TryInfo &one, size_t nb
 static size_t rows_lds_bytes(const QParams &P, u32 chunk) {
   size_t b = 2 * sizeof(u32) * (size_t)chunk + sizeof(TryInfo) * (size_t)P.T + sizeof(u32) * (size_t)P.T + 16;
   b = (b + 15) & ~(size_t)15;
-  if (!d_is_fast(P.d)) b += sizeof(FT) * (size_t)P.d * (1 + 4);
+  if (d_needs_lds_row(P.d)) b += sizeof(FT) * (size_t)P.d * (1 + 4);
   return b;
 }
 
@@ -932,7 +945,7 @@ extern "C" void annhip_recall_ranks(size_t n, size_t d, size_t k, const ftype *p
     hipLaunchKernelGGL(recall_scan_kernel<DD>, dim3(tiles, qgroups), dim3(64 * wpb), smem_s, 0, pts, (u32)n, (int)d, \
                        (int)Q, (int)k, y, gd, self, hist);                                                        \
   } while (0)
-  ANN_DISPATCH_D((int)d, CALL);
+  ANN_DISPATCH_D2((int)d, CALL);
 #undef CALL
   HIPCHECK(hipGetLastError());
   // rank[j] = #points closer than guess j = sum of hist[c] over the c's whose point is closer than gdist[j]:

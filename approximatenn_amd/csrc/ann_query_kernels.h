@@ -108,6 +108,39 @@ __global__ __launch_bounds__(256) void codes_kernel(QParams P, int Q, const FT *
       for (int m = 32; m >= 1; m >>= 1) code |= __shfl_xor(code, m);
       if (lane == 0) codes[(size_t)q * P.T + t] = code;
     }
+  } else if constexpr (D < 0) {
+    constexpr int C = -D;
+    const int oc = P.d / (ANN_VEC * C), rpw = ANN_WAVE / oc;
+    const int g = lane / oc, p = lane - g * oc;
+    const long item = (long)blockIdx.x * wpb + w;
+    const bool live = item < (long)Q * P.T;
+    const int q = live ? (int)(item / P.T) : 0, t = live ? (int)(item % P.T) : 0;
+    VT a[C];
+    const VT *yp = reinterpret_cast<const VT *>(y + (size_t)q * P.d) + p;
+    const VT *mp = reinterpret_cast<const VT *>(P.means) + p;
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+      VT yv = yp[c * oc], mv = mp[c * oc];
+      FT *o = reinterpret_cast<FT *>(&a[c]);
+      const FT *py = reinterpret_cast<const FT *>(&yv), *pm = reinterpret_cast<const FT *>(&mv);
+#pragma unroll
+      for (int j = 0; j < ANN_VEC; j++) o[j] = py[j] - pm[j];
+    }
+    u32 code = 0;
+    for (int s0 = 0; s0 < P.ds; s0 += rpw) {
+      const int sidx = s0 + g;
+      const bool act = g < rpw && sidx < P.ds;
+      const VT *bp = reinterpret_cast<const VT *>(P.bases + ((size_t)t * P.ds + (act ? sidx : 0)) * P.d) + p;
+      VT b[C];
+#pragma unroll
+      for (int c = 0; c < C; c++) b[c] = bp[c * oc];
+      FT v = row_reduce_oc<C, ROW_PRODUCT>(a, b, oc, p);
+      u32 sign = (u32)(ft_bits(v) >> (sizeof(FT) * 8 - 1));
+      if (act && p == 0 && sign) code |= 1u << (P.ds - 1 - sidx);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) code |= __shfl_xor(code, m);
+    if (live && lane == 0) codes[item] = code;
   } else {
     const long item = (long)blockIdx.x * wpb + w;
     const bool live = item < (long)Q * P.T;
@@ -202,7 +235,7 @@ __device__ __forceinline__ void sel_shrink(SelState &S) {
 // the keys that can still matter.  D > 0: LPR lanes per row, the next pass is prefetched while this one is reduced.
 template <int D>
 __device__ __forceinline__ void gather_select(const QParams &P, const u32 *list, int cnt, int alias, u32 x,
-                                              const VT (&a)[D > 0 ? RowLay<(D > 0 ? D : 16)>::C : 1],
+                                              const VT (&a)[RowChunks<D>::C],
                                               const FT *yq, FT *scratch, SelState &S) {
   const int lane = lane_id();
   if constexpr (D > 0) {
@@ -237,6 +270,41 @@ __device__ __forceinline__ void gather_select(const QParams &P, const u32 *list,
         if (pass) S.kbuf[S.kcnt + mask_rank(mm)] = key;
         S.kcnt += __popcll(mm);
         if (S.kcnt + L::RPW > S.cap) sel_shrink(S);
+      }
+    }
+  } else if constexpr (D < 0) {
+    constexpr int C = -D;
+    const int oc = P.d / (ANN_VEC * C), rpw = ANN_WAVE / oc;
+    const int g = lane / oc, p = lane - g * oc;  // lanes with g == rpw have no row
+    VT bn[C];
+    u32 idn = 0;
+    if (cnt > 0) {
+      idn = list[(g < rpw && g < cnt) ? g : 0];
+      const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(idn - P.lo) * P.d) + p;
+#pragma unroll
+      for (int c = 0; c < C; c++) bn[c] = load_row_chunk<true>(rp + c * oc);
+    }
+    for (int base = 0; base < cnt; base += rpw) {
+      VT b[C];
+#pragma unroll
+      for (int c = 0; c < C; c++) b[c] = bn[c];
+      const u32 id = idn;
+      const bool act = g < rpw && base + g < cnt && !(alias && id == x);
+      const int nb = base + rpw;
+      if (nb < cnt) {
+        idn = list[(g < rpw && nb + g < cnt) ? nb + g : nb];
+        const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(idn - P.lo) * P.d) + p;
+#pragma unroll
+        for (int c = 0; c < C; c++) bn[c] = load_row_chunk<true>(rp + c * oc);
+      }
+      const FT dist = row_reduce_oc<C, ROW_SQDIFF>(a, b, oc, p);
+      const Key key = key_make(dist, id);
+      const bool pass = act && p == 0 && key_less(key, S.tau);
+      const u64 mm = __ballot(pass);
+      if (mm) {
+        if (pass) S.kbuf[S.kcnt + mask_rank(mm)] = key;
+        S.kcnt += __popcll(mm);
+        if (S.kcnt + rpw > S.cap) sel_shrink(S);
       }
     }
   } else {
@@ -309,12 +377,17 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
   u32 vtot = 0, vown = 0;
 
   // the query row, as this lane's slice
-  VT a[D > 0 ? RowLay<(D > 0 ? D : 16)>::C : 1];
+  VT a[RowChunks<D>::C];
   if constexpr (D > 0) {
     typedef RowLay<D> L;
     const VT *yp = reinterpret_cast<const VT *>(y + (size_t)x * D) + (lane % L::LPR);
 #pragma unroll
     for (int c = 0; c < L::C; c++) a[c] = yp[c * L::LPR];
+  } else if constexpr (D < 0) {
+    const int oc = P.d / (ANN_VEC * -D);
+    const VT *yp = reinterpret_cast<const VT *>(y + (size_t)x * P.d) + (lane % oc);
+#pragma unroll
+    for (int c = 0; c < -D; c++) a[c] = yp[c * oc];
   }
 
   int cnt = 0;
@@ -630,12 +703,17 @@ __global__ __launch_bounds__(256) void row_dists_kernel(QParams P, int Q, const 
     }
   if constexpr (D == 0)
     for (int z = threadIdx.x; z < P.d; z += blockDim.x) yq[z] = y[(size_t)x * P.d + z];
-  VT a[D > 0 ? RowLay<(D > 0 ? D : 16)>::C : 1];
+  VT a[RowChunks<D>::C];
   if constexpr (D > 0) {
     typedef RowLay<D> L;
     const VT *yp = reinterpret_cast<const VT *>(y + (size_t)x * D) + (lane % L::LPR);
 #pragma unroll
     for (int c = 0; c < L::C; c++) a[c] = yp[c * L::LPR];
+  } else if constexpr (D < 0) {
+    const int oc = P.d / (ANN_VEC * -D);
+    const VT *yp = reinterpret_cast<const VT *>(y + (size_t)x * P.d) + (lane % oc);
+#pragma unroll
+    for (int c = 0; c < -D; c++) a[c] = yp[c * oc];
   }
   u32 gathered = 0;
   // gridDim.y workgroups share one row: each takes every gridDim.y-th chunk of its slots
@@ -689,6 +767,21 @@ __global__ __launch_bounds__(256) void row_dists_kernel(QParams P, int Q, const 
 #pragma unroll
         for (int c = 0; c < L::C; c++) b[c] = load_row_chunk<true>(rp + c * L::LPR);
         const FT dist = row_reduce<D, ROW_SQDIFF>(a, b);
+        if (act && p == 0) dist_row[lslot[r]] = dist;
+      }
+    } else if constexpr (D < 0) {
+      constexpr int C = -D;
+      const int oc = P.d / (ANN_VEC * C), rpw = ANN_WAVE / oc;
+      const int g = lane / oc, p = lane - g * oc;
+      for (int base = w * rpw; base < cnt; base += W * rpw) {
+        const int r = base + g;
+        const bool act = g < rpw && r < cnt;
+        const u32 id = lid[act ? r : base];
+        const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(id - P.lo) * P.d) + p;
+        VT b[C];
+#pragma unroll
+        for (int c = 0; c < C; c++) b[c] = load_row_chunk<true>(rp + c * oc);
+        const FT dist = row_reduce_oc<C, ROW_SQDIFF>(a, b, oc, p);
         if (act && p == 0) dist_row[lslot[r]] = dist;
       }
     } else {
