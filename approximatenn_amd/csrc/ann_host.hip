@@ -481,10 +481,13 @@ static int stage1_cap(int W, int K1) {
   if (cap < K1 + 128) cap = K1 + 128;
   return (cap + 63) & ~63;
 }
-static size_t stage1_lds_bytes(const QParams &P, int W, int K1, int cap) {
+static size_t stage1_lds_bytes(const QParams &P, int W, int K1, int cap, u32 tail_len = 0) {
   size_t b = sizeof(Key) * (size_t)W * cap + 2 * sizeof(Key) * (size_t)W * K1 + sizeof(TryInfo) * (size_t)P.T +
              sizeof(u32 *) * (size_t)W * ANN_WAVE + sizeof(u32) * (size_t)W * ANN_S1_CHUNK +
-             sizeof(u32) * (size_t)W * ANN_WAVE + sizeof(u32) * (size_t)P.T + sizeof(int) * (size_t)W + sizeof(u32) * 2;
+             sizeof(u32) * (size_t)W * ANN_WAVE + sizeof(u32) * (size_t)P.T + sizeof(int) * (size_t)W + sizeof(u32) * 4 +
+             3 * sizeof(u32) * (size_t)tail_len;
+  b = (b + 15) & ~(size_t)15;
+  b += sizeof(FT) * (size_t)tail_len;
   b = (b + 15) & ~(size_t)15;
   if (d_needs_lds_row(P.d)) b += sizeof(FT) * (size_t)P.d * (1 + W);
   return b;
@@ -504,10 +507,10 @@ __global__ void sum_u32_kernel(size_t count, const u32 *__restrict__ v, unsigned
 
 static void launch_stage1(annhip_index *ix, const QParams &P, size_t Q, const FT *y, int alias,
                           const u32 *codes, FT *cand_d, u32 *cand_i, u32 *nvt, u32 *nvo, hipStream_t s,
-                          const std::vector<TryInfo> &h_tries, bool use_seg) {
+                          const std::vector<TryInfo> &h_tries, bool use_seg, FusedTail F = FusedTail{0, 0, NULL, NULL, NULL, NULL, NULL}) {
   if (!Q) return;
   const int K1 = P.k + 1, W = stage1_waves(P.P1, (double)(P.hi - P.lo) / (double)P.n), cap = stage1_cap(W, K1);
-  const size_t smem = stage1_lds_bytes(P, W, K1, cap);
+  const size_t smem = stage1_lds_bytes(P, W, K1, cap, F.enabled ? F.len2 : 0);
   u32 runs_used = 0;  // (try, hamming neighbour) runs that start below P1, in slot order
   for (int t = 0; t < P.T; t++)
     for (int yy = 0; yy <= P.ds; yy++)
@@ -531,11 +534,11 @@ static void launch_stage1(annhip_index *ix, const QParams &P, size_t Q, const FT
     if (use_seg) {                                                                                          \
       allow_lds(stage1_select_kernel<DD, true>, smem);                                                      \
       hipLaunchKernelGGL((stage1_select_kernel<DD, true>), dim3((unsigned)Q), dim3(64 * W), smem, s, P, (int)Q, y, \
-                         alias, codes, K1, cap, runs_used, cand_d, cand_i, nvt, nvo);                       \
+                         alias, codes, K1, cap, runs_used, cand_d, cand_i, nvt, nvo, F);                    \
     } else {                                                                                                \
       allow_lds(stage1_select_kernel<DD, false>, smem);                                                     \
       hipLaunchKernelGGL((stage1_select_kernel<DD, false>), dim3((unsigned)Q), dim3(64 * W), smem, s, P, (int)Q, y, \
-                         alias, codes, K1, cap, runs_used, cand_d, cand_i, nvt, nvo);                       \
+                         alias, codes, K1, cap, runs_used, cand_d, cand_i, nvt, nvo, F);                    \
     }                                                                                                       \
   } while (0)
   ANN_DISPATCH_D(P.d, CALL);
@@ -617,7 +620,7 @@ static void launch_rows(const QParams &P, size_t Q, const FT *y, int alias, cons
 // network + rdups + network on nq rows of reference length L, `len` stored entries, row stride in_stride
 static void launch_exact_select(u32 L, u32 len, u32 in_stride, int k, size_t nq, u32 *ids, FT *dist,
                                 const u32 *qidx, u32 xbase, u32 *out_i, FT *out_d, int ostride, int ooff,
-                                hipStream_t s, const u32 *live_rows = NULL) {
+                                hipStream_t s, const u32 *live_rows = NULL, size_t *out64 = NULL) {
   if (!nq) return;
   const int lk = ann_lg(L);
   unsigned npairs = 8u << (lk > 4 ? lk - 4 : 0);
@@ -628,10 +631,10 @@ static void launch_exact_select(u32 L, u32 len, u32 in_stride, int k, size_t nq,
   if (smem <= 150 * 1024) {  // the whole row in LDS (one CU has 160 KB); longer rows sort in place in HBM
     allow_lds(exact_select_kernel<true>, smem);
     hipLaunchKernelGGL(exact_select_kernel<true>, dim3(grid), dim3(block), smem, s, L, len, in_stride, k,
-                       ids, dist, qidx, xbase, out_i, out_d, ostride, ooff, live_rows, (u32)nq);
+                       ids, dist, qidx, xbase, out_i, out_d, ostride, ooff, live_rows, (u32)nq, out64);
   } else
     hipLaunchKernelGGL(exact_select_kernel<false>, dim3(grid), dim3(block), 0, s, L, len, in_stride, k,
-                       ids, dist, qidx, xbase, out_i, out_d, ostride, ooff, live_rows, (u32)nq);
+                       ids, dist, qidx, xbase, out_i, out_d, ostride, ooff, live_rows, (u32)nq, out64);
   HIPCHECK(hipGetLastError());
 }
 
@@ -726,6 +729,41 @@ static long query_impl(annhip_index *ix, annhip_workspace &ws, hipStream_t s, si
   FT *top_d = (FT *)ws.top_d.need(sizeof(FT) * Q * k);
   FT *cand_d = NULL;
   u32 *cand_i = NULL, *nvt = NULL;
+  // ---- fused path: stage 2 runs in the tail of every query's stage-1 workgroup; only rejected queries come back
+  {
+    const size_t xrow = (size_t)P.Lc1 * (sizeof(FT) + sizeof(u32));
+    const bool whole = ix->lo == 0 && ix->hi == ix->n;
+    // Measured: +5 % at Q = 1k (launch-bound), neutral at cfg3 (Q = 10k, d = 128), -6 % at Q = 10k, d = 64 -- the tail
+    // keeps the workgroup's registers/LDS occupied through a chain of dependent loads.  So: small batches only.
+    const char *fenv = getenv("ANN_HIP_FUSE");  // "0" = never, "1" = whenever possible (A/B switch)
+    const bool want = fenv ? atoi(fenv) != 0 : Q <= 2048;
+    if (mode == 0 && whole && want && P.Lc2 <= 1024 && Q * xrow <= ((size_t)1 << 30)) {
+      FT *out_d = dists_dev ? reinterpret_cast<FT *>(dists_dev) : (FT *)ws.out_d.need(sizeof(FT) * Q * k);
+      u32 *fl = (u32 *)ws.flist.need(sizeof(u32) * Q);
+      u32 *nvo = (u32 *)ws.nvo.need(sizeof(u32) * Q);
+      zero_u32_kernel<<<1, 1, 0, s>>>(ws.d_fcount);
+      FusedTail F{1, P.Lc2, ids_dev, out_d, fl, ws.d_fcount, ix->d_rows + 2};
+      launch_stage1(ix, P, Q, y, alias, codes, NULL, NULL, NULL, nvo, s, ix->h_tries, ix->use_seg, F);
+      seg_mark(ix, marks, s);
+      // rejected queries (device-side count, normally zero): exact stage 1, then the classic stage 2, for them only
+      unsigned long long *rows_ctr = ix->profile ? ix->d_rows + 8 : NULL;
+      u32 *xi = (u32 *)ws.xids.need(sizeof(u32) * Q * P.Lc1);
+      FT *xd = (FT *)ws.xd.need(sizeof(FT) * Q * P.Lc1);
+      launch_rows<MODE_TABLE>(P, Q, y, alias, codes, fl, 0, Q, P.Lc1, NULL, NULL, xi, xd, rows_ctr, s, ws.d_fcount);
+      launch_exact_select(P.L1, P.Lc1, P.Lc1, k, Q, xi, xd, fl, 0, top_i, top_d, k, 0, s, ws.d_fcount);
+      seg_mark(ix, marks, s);
+      u32 *r2i = (u32 *)ws.r2i.need(sizeof(u32) * Q * P.Lc2);
+      FT *r2d = (FT *)ws.r2d.need(sizeof(FT) * Q * P.Lc2);
+      launch_rows<MODE_GRAPH>(P, Q, y, alias, NULL, fl, 0, Q, P.Lc2, top_i, top_d, r2i, r2d, rows_ctr, s, ws.d_fcount);
+      seg_mark(ix, marks, s);
+      launch_exact_select(P.L2, P.Lc2, P.Lc2, k, Q, r2i, r2d, fl, 0, NULL, out_d, k, 0, s, ws.d_fcount, ids_dev);
+      seg_mark(ix, marks, s);
+      seg_mark(ix, marks, s);
+      if (marks) ix->seg_used.push_back(marks_store);
+      ix->queries += (double)Q;
+      return -1;
+    }
+  }
   if (mode == 0) {
     cand_d = (FT *)ws.cand_d.need(sizeof(FT) * Q * K1);
     cand_i = (u32 *)ws.cand_i.need(sizeof(u32) * Q * K1);

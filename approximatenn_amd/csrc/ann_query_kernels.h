@@ -332,6 +332,21 @@ __device__ __forceinline__ void gather_select(const QParams &P, const u32 *list,
 // (+inf, ANN_ID_NONE)); nv_tot = valid slots below P1 on ANY device -- with SEG an upper bound that ignores the
 // self exclusion (only used for finalize1's "is there an +inf in the prefix" test, where an over-estimate merely
 // sends a query to the exact path); nv_own = rows this device gathered.
+// Optional fused tail of stage1_select (single-device query path): instead of handing the k+1 candidates to
+// finalize1 / row_dists<GRAPH> / exact_select / widen_ids (four more launches, each with its drain and fill), the
+// query's own workgroup applies the finalize1 test, and -- unless the query has to take the exact path -- builds the
+// stage-2 row (supercharge, compute.cl:252-263), gathers the <= k*k neighbour-of-neighbour rows, runs the reference's
+// network on the L2-entry row in LDS and writes the final size_t ids and distances.  Rejected queries are appended to
+// `flist`; the host runs the separate exact path for them afterwards (device-driven, normally zero rows).
+struct FusedTail {
+  int enabled;          // 0: classic path (multi-GPU staged calls, precomp, long stage-2 rows)
+  u32 len2;             // Lc2 = ann_need_len(L2, k)
+  size_t *out_ids;      // [Q][k]
+  FT *out_dist;         // [Q][k]
+  u32 *flist, *fcount;  // rejected queries
+  unsigned long long *exact_total;
+};
+
 template <int D, bool SEG>
 __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, const FT *__restrict__ y,
                                                             int alias, const u32 *__restrict__ codes,
@@ -339,7 +354,7 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
                                                             FT *__restrict__ cand_dist,
                                                             u32 *__restrict__ cand_id,
                                                             u32 *__restrict__ nv_tot,
-                                                            u32 *__restrict__ nv_own) {
+                                                            u32 *__restrict__ nv_own, FusedTail F) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = lane_id(), w = threadIdx.x >> 6, W = blockDim.x >> 6;
   const u32 x = blockIdx.x;
@@ -354,7 +369,13 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
   u32 *pref_all = reinterpret_cast<u32 *>(sp);           sp += sizeof(u32) * (size_t)W * ANN_WAVE;
   u32 *qcode = reinterpret_cast<u32 *>(sp);              sp += sizeof(u32) * (size_t)P.T;
   int *mcnt = reinterpret_cast<int *>(sp);               sp += sizeof(int) * (size_t)W;
-  u32 *cnts = reinterpret_cast<u32 *>(sp);               sp += sizeof(u32) * 2;
+  u32 *cnts = reinterpret_cast<u32 *>(sp);               sp += sizeof(u32) * 4;  // [0] valid [1] gathered [2] tail list [3] rejected
+  const size_t tl = F.enabled ? F.len2 : 0;
+  u32 *t_ids = reinterpret_cast<u32 *>(sp);              sp += sizeof(u32) * tl;
+  u32 *t_slot = reinterpret_cast<u32 *>(sp);             sp += sizeof(u32) * tl;
+  u32 *t_gid = reinterpret_cast<u32 *>(sp);              sp += sizeof(u32) * tl;
+  sp = smem + (((sp - smem) + 15) & ~(size_t)15);
+  FT *t_dist = reinterpret_cast<FT *>(sp);               sp += sizeof(FT) * tl;
   sp = smem + (((sp - smem) + 15) & ~(size_t)15);
   FT *yq = reinterpret_cast<FT *>(sp);  // generic d only: [d] + W*[d]
   u32 *list = list_all + (size_t)w * ANN_S1_CHUNK;
@@ -365,7 +386,7 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
     tries[i] = P.tries[i];
     qcode[i] = codes[(size_t)i * Q + x];  // Q2: read layout [try][query]
   }
-  if (threadIdx.x < 2) cnts[threadIdx.x] = 0;
+  if (threadIdx.x < 4) cnts[threadIdx.x] = 0;
   if constexpr (D == 0)
     for (int z = threadIdx.x; z < P.d; z += blockDim.x) yq[z] = y[(size_t)x * P.d + z];
   __syncthreads();
@@ -487,14 +508,106 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
     }
     wave_lds_sync();
     const int m = wave_select_smallest(S.kbuf, total, K1, S.kout);
-    for (int i = lane; i < K1; i += ANN_WAVE) {
-      cand_dist[(size_t)x * K1 + i] = i < m ? key_dist(S.kout[i]) : ft_inf();
-      cand_id[(size_t)x * K1 + i] = i < m ? key_id(S.kout[i]) : ANN_ID_NONE;
+    if (!F.enabled) {
+      for (int i = lane; i < K1; i += ANN_WAVE) {
+        cand_dist[(size_t)x * K1 + i] = i < m ? key_dist(S.kout[i]) : ft_inf();
+        cand_id[(size_t)x * K1 + i] = i < m ? key_id(S.kout[i]) : ANN_ID_NONE;
+      }
+      if (lane == 0) {
+        nv_tot[x] = cnts[0];
+        nv_own[x] = cnts[1];  // per-query count; never a same-address atomic from every workgroup (fan-in ~12 ns each)
+      }
+    } else {
+      // the finalize1 test (see finalize1_kernel): >= k finite distinct keys, no shared distance, an +inf in the prefix
+      const int k = K1 - 1;
+      bool bad = m < k;
+      for (int t = lane; t + 1 < m; t += ANN_WAVE)
+        if (ft_bits(key_dist(S.kout[t])) == ft_bits(key_dist(S.kout[t + 1]))) bad = true;
+      if (m >= k && !(key_dist(S.kout[k - 1]) < ft_inf())) bad = true;
+      if (P.L1 > P.P1 && cnts[0] >= P.P1) bad = true;
+      const bool reject = __ballot(bad) != 0;
+      if (lane == 0) {
+        cnts[3] = reject ? 1u : 0u;
+        if (reject) {
+          F.flist[atomicAdd(F.fcount, 1u)] = x;
+          atomicAdd(F.exact_total, 1ull);
+        }
+      }
     }
-    if (lane == 0) {
-      nv_tot[x] = cnts[0];
-      nv_own[x] = cnts[1];  // per-query count; never a same-address atomic from every workgroup (fan-in ~12 ns each)
+  }
+  if (!F.enabled) return;
+  __syncthreads();
+  if (cnts[3]) {  // exact path later; only the statistics are written here
+    if (threadIdx.x == 0) nv_own[x] = cnts[1];
+    return;
+  }
+  // ---- fused stage 2 (det_results second half, alg.c:314-327) on this query's own workgroup
+  {
+    const int k = K1 - 1;
+    const Key *top = kout_all;  // wave 0's sorted survivors: the stage-1 top-k
+    for (u32 j = threadIdx.x; j < F.len2; j += blockDim.x) {
+      u32 id;
+      if (j < (u32)k) {
+        id = key_id(top[j]);
+        t_dist[j] = key_dist(top[j]);
+      } else {
+        const u32 parent = key_id(top[j / k - 1]), z = j % k;
+        id = parent < P.n ? P.graph[(size_t)parent * k + z] : (P.graph[z] | P.n);  // supercharge, Q7
+        const bool ok = id < P.n && !(alias && id == x) && id >= P.lo && id < P.hi;
+        if (ok) {
+          const u32 pos = atomicAdd(&cnts[2], 1u);
+          t_slot[pos] = j;
+          t_gid[pos] = id;
+        } else {
+          t_dist[j] = ft_inf();
+        }
+      }
+      t_ids[j] = id;
     }
+    __syncthreads();
+    const int cnt2 = (int)cnts[2];
+    if constexpr (D > 0) {
+      typedef RowLay<D> L;
+      const int p = lane % L::LPR, g = lane / L::LPR;
+      for (int base = w * L::RPW; base < cnt2; base += W * L::RPW) {
+        const int r = base + g;
+        const bool act = r < cnt2;
+        const u32 id = t_gid[act ? r : base];
+        const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(id - P.lo) * D) + p;
+        VT b[L::C];
+#pragma unroll
+        for (int c = 0; c < L::C; c++) b[c] = load_row_chunk<true>(rp + c * L::LPR);
+        const FT dist = row_reduce<D, ROW_SQDIFF>(a, b);
+        if (act && p == 0) t_dist[t_slot[r]] = dist;
+      }
+    } else if constexpr (D < 0) {
+      constexpr int C = -D;
+      const int oc = P.d / (ANN_VEC * C), rpw = ANN_WAVE / oc;
+      const int g = lane / oc, p = lane - g * oc;
+      for (int base = w * rpw; base < cnt2; base += W * rpw) {
+        const int r = base + g;
+        const bool act = g < rpw && r < cnt2;
+        const u32 id = t_gid[act ? r : base];
+        const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(id - P.lo) * P.d) + p;
+        VT b[C];
+#pragma unroll
+        for (int c = 0; c < C; c++) b[c] = load_row_chunk<true>(rp + c * oc);
+        const FT dist = row_reduce_oc<C, ROW_SQDIFF>(a, b, oc, p);
+        if (act && p == 0) t_dist[t_slot[r]] = dist;
+      }
+    } else {
+      for (int r = w; r < cnt2; r += W) {
+        const FT dist = row_reduce_generic<ROW_SQDIFF>(P.d, yq, P.points + (size_t)(t_gid[r] - P.lo) * P.d, scratch);
+        if (lane == 0) t_dist[t_slot[r]] = dist;
+      }
+    }
+    __syncthreads();
+    block_topk_stage<true>((size_t)k * (k + 1), F.len2, t_dist, t_ids);  // sort_and_uniq, alg.c:327
+    for (int t = threadIdx.x; t < k; t += blockDim.x) {
+      F.out_ids[(size_t)x * k + t] = t_ids[t];
+      F.out_dist[(size_t)x * k + t] = t_dist[t];
+    }
+    if (threadIdx.x == 0) nv_own[x] = cnts[1] + (u32)cnt2;  // rows gathered for this query, both stages
   }
 }
 
@@ -813,7 +926,7 @@ __global__ __launch_bounds__(1024) void exact_select_kernel(u32 L, u32 len, u32 
                                                            u32 *__restrict__ out_id,
                                                            FT *__restrict__ out_dist, int ostride,
                                                            int ooff, const u32 *__restrict__ live_rows,
-                                                           u32 nrows) {
+                                                           u32 nrows, size_t *__restrict__ out64) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (live_rows) nrows = min(nrows, *live_rows);  // persistent grid over the device-side row count
   for (u32 row = blockIdx.x; row < nrows; row += gridDim.x) {
@@ -827,13 +940,15 @@ __global__ __launch_bounds__(1024) void exact_select_kernel(u32 L, u32 len, u32 
     __syncthreads();
     block_topk_stage<true>(L, len, sd, si);
     for (int t = threadIdx.x; t < k; t += blockDim.x) {
-      out_id[(size_t)x * ostride + ooff + t] = si[t];
+      if (out64) out64[(size_t)x * ostride + ooff + t] = si[t];  // straight to the ABI's size_t ids
+      else out_id[(size_t)x * ostride + ooff + t] = si[t];
       out_dist[(size_t)x * ostride + ooff + t] = sd[t];
     }
   } else {
     block_topk_stage<false>(L, len, gd, gi);
     for (int t = threadIdx.x; t < k; t += blockDim.x) {
-      out_id[(size_t)x * ostride + ooff + t] = gi[t];
+      if (out64) out64[(size_t)x * ostride + ooff + t] = gi[t];
+      else out_id[(size_t)x * ostride + ooff + t] = gi[t];
       out_dist[(size_t)x * ostride + ooff + t] = gd[t];
     }
   }

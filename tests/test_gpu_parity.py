@@ -21,15 +21,19 @@ def _check(ids, dists, g_ids, g_dists, what):
     assert bits_equal(dists, g_dists), "%s: distances not bit-identical" % what
 
 
-@pytest.fixture(params=["select", "exact"])
+@pytest.fixture(params=["select", "select-unfused", "exact"])
 def path_mode(request):
-    """'select' = production path (selection + exact fallback); 'exact' = the reference network for every row."""
+    """'select' = production path (selection + exact fallback; small batches take the fused stage-2 tail);
+    'select-unfused' = the same with the separate stage-2 kernels; 'exact' = the reference network for every row."""
+    os.environ.pop("ANN_HIP_EXACT", None)
+    os.environ.pop("ANN_HIP_FUSE", None)
     if request.param == "exact":
         os.environ["ANN_HIP_EXACT"] = "1"
-    else:
-        os.environ.pop("ANN_HIP_EXACT", None)
+    elif request.param == "select-unfused":
+        os.environ["ANN_HIP_FUSE"] = "0"
     yield request.param
     os.environ.pop("ANN_HIP_EXACT", None)
+    os.environ.pop("ANN_HIP_FUSE", None)
 
 
 @pytest.mark.parametrize("name", golden_cases())
