@@ -225,7 +225,10 @@ def main():
 
 
 def cpu_baseline(args, ix, points, y_dev, libc):
-    """Oracle (oracle/ann_oracle.c, single thread) on a bounded sample, on the same index, checked against the GPU."""
+    """CPU column on the GPU box's host cores, single thread, on a bounded sample of the same batch and the same
+    (GPU-built) index, with the results compared against the GPU's.  kind = "reference": the reference's own query_cpu
+    (oracle/_ref, compiled from /root/reference in the authoring container; it materialises Q*L1*d values, so the
+    sample is small); otherwise kind = "port": the oracle (oracle/ann_oracle.c).  The oracle's rate is reported too."""
     import numpy as np
     import torch
 
@@ -234,26 +237,42 @@ def cpu_baseline(args, ix, points, y_dev, libc):
     arrays = save.to_dict()
     save.free()
     host_pts = points.cpu().numpy()
+    npdt = np.float32 if args.dtype == "f32" else np.float64
+
+    def timed(backend, qs):
+        y = np.ascontiguousarray(y_dev[:qs].cpu().numpy())
+        hs = O.HostSave(arrays, args.dtype)
+        t0 = time.perf_counter()
+        ids, dd = backend.query(hs, host_pts, y)
+        dt = time.perf_counter() - t0
+        g_ids, g_d, _ = ix.query(y_dev[:qs].contiguous())
+        torch.cuda.synchronize()
+        same = {"ids_bit_exact": bool(np.array_equal(g_ids.cpu().numpy().astype(np.uint64), ids)),
+                "dists_bit_exact": bool(np.array_equal(g_d.cpu().numpy().view(np.uint8), dd.view(np.uint8)))}
+        return qs / dt, dt, same
+
+    def sized(backend, budget_s, probe, cap, derate=1.0):
+        rate, _, _ = timed(backend, probe)
+        qs = int(max(probe, min(cap, len(y_dev), rate * budget_s * derate)))
+        return (qs,) + timed(backend, qs)
+
     orc = O.CpuBackend(args.dtype, "oracle")
-    hs = O.HostSave(arrays, args.dtype)
-    qs = 64
-    y = y_dev[:qs].cpu().numpy()
-    t0 = time.perf_counter()
-    orc.query(hs, host_pts, y)
-    rate = qs / (time.perf_counter() - t0)
-    qs = int(max(64, min(len(y_dev), rate * args.cpu_seconds)))
-    y = np.ascontiguousarray(y_dev[:qs].cpu().numpy())
-    t0 = time.perf_counter()
-    o_ids, o_d = orc.query(hs, host_pts, y)
-    cpu_s = time.perf_counter() - t0
-    g_ids, g_d, _ = ix.query(y_dev[:qs].contiguous())
-    torch.cuda.synchronize()
-    ids_equal = bool(np.array_equal(g_ids.cpu().numpy().astype(np.uint64), o_ids))
-    d_equal = bool(np.array_equal(g_d.cpu().numpy().view(np.uint8), o_d.view(np.uint8)))
-    return {"value": round(qs / cpu_s, 2), "unit": "queries/s", "cores": 1, "kind": "port",
-            "sample": "%d-query batch of the same workload on the GPU-built index (oracle, 1 thread, %.1f s)" % (qs, cpu_s),
-            "host_cores_available": os.cpu_count(),
-            "parity_on_sample": {"ids_bit_exact": ids_equal, "dists_bit_exact": d_equal}}
+    o_qs, o_rate, o_dt, o_same = sized(orc, args.cpu_seconds, 64, len(y_dev))
+    out = {"value": round(o_rate, 2), "unit": "queries/s", "cores": 1, "kind": "port",
+           "sample": "%d-query batch of the same workload on the GPU-built index (oracle, 1 thread, %.1f s)" % (o_qs, o_dt),
+           "host_cores_available": os.cpu_count(), "parity_on_sample": o_same}
+    if O.have_ref():
+        # memory of the reference's diffs tensor: Q * L1 * d values -- keep it under ~8 GB
+        cap = max(8, int(8e9 / (ix.L1 * ix.d * np.dtype(npdt).itemsize)))
+        ref = O.CpuBackend(args.dtype, "ref")
+        # its per-query cost grows with the batch (strided z-outer loops, ocl2c.h:18-22): derate the probe's estimate
+        r_qs, r_rate, r_dt, r_same = sized(ref, args.cpu_seconds, 32, min(cap, 1000), derate=0.35)
+        out = {"value": round(r_rate, 2), "unit": "queries/s", "cores": 1, "kind": "reference",
+               "sample": "%d-query batch of the same workload on the GPU-built index (the reference's query_cpu, "
+                         "oracle/_ref, 1 thread, %.1f s)" % (r_qs, r_dt),
+               "host_cores_available": os.cpu_count(), "parity_on_sample": r_same,
+               "oracle_port": {"value": round(o_rate, 2), "sample_queries": o_qs, "parity_on_sample": o_same}}
+    return out
 
 
 if __name__ == "__main__":
