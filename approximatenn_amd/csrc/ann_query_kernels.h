@@ -1,18 +1,21 @@
 // ann_query_kernels.h -- HIP kernels of the query()/det_results hot path (gfx950).
 //
 // What the reference does with ~250 OpenCL launches and a materialised [Q][L1][d] tensor
-// (/root/reference/alg.c:458-519, 303-337) is done here by five kernels:
+// (/root/reference/alg.c:458-519, 303-337) is done here by a handful of kernels:
 //
 //   codes_kernel        y - means, projection onto bases, sign hash            (alg.c:462-492)
-//   stage1_select       candidate ids from the bucket tables, row gather, squared L2 in the exact
-//                       tree order, and selection of the k+1 smallest distinct (dist,id) keys
-//                       -- no sort network, no materialised distances          (alg.c:493-500,308-312)
+//   stage1_select       candidate ids from the bucket tables (per-bucket segment words), row gather, squared L2 in
+//                       the exact tree order, and selection of the k+1 smallest distinct (dist,id) keys
+//                       -- no sort network, no materialised distances          (alg.c:493-500,308-312);
+//                       optionally (small batches) the whole of stage 2 in the workgroup's tail (FusedTail)
+//   stage1_bucket       precomp's second_half, one workgroup per bucket        (alg.c:245-290)
 //   finalize1           proves the selection equals sort/rdups/sort (no ties between different ids
 //                       among the k+1 best, >= k finite, an +inf inside the sorted prefix) or flags
 //                       the query for the exact path
 //   row_dists           exact path / stage 2: every needed slot's id and distance, in slot order
 //                       (shufcomp alg.c:438-452, supercharge compute.cl:252-263, compdists alg.c:233-242)
 //   exact_select        the reference's network + rdups + network, literally    (alg.c:224-230)
+//   merge_candidates    multi-GPU: G sorted candidate lists -> the k+1 globally best
 //
 // Only slots below ann_need_len() are ever produced.
 #pragma once
