@@ -70,6 +70,13 @@ def load(prec="f32"):
     lib.annhip_workspace_destroy.argtypes = [vp]
     lib.annhip_query_on.restype = C.c_long
     lib.annhip_query_on.argtypes = [vp, vp, vp, sz, vp, C.c_int, C.c_int, vp, vp]
+    lib.annhip_stream_open.restype = vp
+    lib.annhip_stream_open.argtypes = [vp, sz, C.c_int]
+    lib.annhip_stream_submit.restype = C.c_long
+    lib.annhip_stream_submit.argtypes = [vp, sz, vp, C.c_int]
+    lib.annhip_stream_collect.restype = C.c_int
+    lib.annhip_stream_collect.argtypes = [vp, C.c_long, vp, vp]
+    lib.annhip_stream_close.argtypes = [vp]
     lib.annhip_codes.argtypes = [vp, sz, vp, u32p]
     lib.annhip_stage1_local.argtypes = [vp, sz, vp, C.c_int, u32p, vp, u32p, u32p]
     lib.annhip_merge_candidates.argtypes = [vp, C.c_int, sz, vp, u32p, vp, u32p]
@@ -98,7 +105,8 @@ def load(prec="f32"):
 # every symbol include/*.h declares for the backend library (checked by tests/test_abi.py)
 EXPORTED = ["gpu_init", "gpu_cleanup", "register_cleanup", "query_gpu", "precomp_gpu", "annhip_precision",
             "annhip_index_create", "annhip_index_destroy", "annhip_index_info", "annhip_index_set_stream",
-            "annhip_index_export", "annhip_index_reshard", "annhip_save_write", "annhip_save_read", "annhip_precomp_index", "annhip_query", "annhip_workspace_create", "annhip_workspace_destroy", "annhip_query_on", "annhip_codes", "annhip_stage1_local",
+            "annhip_index_export", "annhip_index_reshard", "annhip_save_write", "annhip_save_read", "annhip_precomp_index", "annhip_query", "annhip_workspace_create", "annhip_workspace_destroy", "annhip_query_on", "annhip_stream_open", "annhip_stream_submit", "annhip_stream_collect", "annhip_stream_close",
+            "annhip_codes", "annhip_stage1_local",
             "annhip_merge_candidates", "annhip_stage1_finalize", "annhip_stage1_rows", "annhip_stage2_rows", "annhip_exact_select",
             "annhip_widen_ids", "annhip_recall_ranks", "annhip_profile", "annhip_stats", "annhip_stage_ms"]
 DISPATCH_EXPORTED = ["precomp", "query", "free_save"]

@@ -157,6 +157,52 @@ def query(save, points, y, want_dists=True):
     return ids, _take(dptr, ycnt * k, cft, _ft(prec)).reshape(ycnt, k)
 
 
+class HostStream:
+    """annhip_stream_*: numpy batches in, numpy results out, up to `lanes` batches in flight.
+
+        hs = ix.host_stream(max_ycnt=10000, lanes=3)
+        for ids, dists in hs.map(batches):      # results in submission order
+            ...
+    """
+
+    def __init__(self, ix, max_ycnt, lanes=3):
+        self.ix, self.lib, self.lanes = ix, ix.lib, lanes
+        self.h = self.lib.annhip_stream_open(ix.h, max_ycnt, lanes)
+        self.ft = _ft(ix.prec)
+        self._pending = {}
+
+    def submit(self, y, alias=False):
+        y = np.ascontiguousarray(y, dtype=self.ft)
+        t = self.lib.annhip_stream_submit(self.h, y.shape[0], y.ctypes.data, int(alias))
+        if t >= 0:
+            self._pending[t] = y.shape[0]
+        return t
+
+    def collect(self, ticket):
+        n = self._pending.pop(ticket)
+        ids = np.empty((n, self.ix.k), dtype=np.uint64)
+        dists = np.empty((n, self.ix.k), dtype=self.ft)
+        if self.lib.annhip_stream_collect(self.h, ticket, ids.ctypes.data, dists.ctypes.data) != 0:
+            raise RuntimeError("unknown ticket %d" % ticket)
+        return ids, dists
+
+    def map(self, batches, alias=False):
+        inflight = []
+        for y in batches:
+            if len(inflight) == self.lanes:
+                yield self.collect(inflight.pop(0))
+            t = self.submit(y, alias)
+            assert t >= 0
+            inflight.append(t)
+        while inflight:
+            yield self.collect(inflight.pop(0))
+
+    def close(self):
+        if self.h:
+            self.lib.annhip_stream_close(self.h)
+            self.h = None
+
+
 def recall_ranks(points, y, guess, self_exclude=False):
     """annhip_recall_ranks: torch device tensors points [n,d], y [Q,d], guess int64 [Q,k] -> int64 ranks [Q,k]
     (number of points strictly closer than each guessed neighbour)."""
@@ -265,6 +311,10 @@ class Index:
             nex = self.lib.annhip_query_on(self.h, ws, stream.cuda_stream if stream is not None else None, Q, y.data_ptr(),
                                            int(alias), mode, ids.data_ptr(), dists.data_ptr())
         return ids, dists, nex
+
+    def host_stream(self, max_ycnt, lanes=3):
+        """annhip_stream_open: pipeline for host-resident (numpy) batches; see HostStream."""
+        return HostStream(self, max_ycnt, lanes)
 
     def profile(self, on=True):
         self.lib.annhip_profile(self.h, int(on))

@@ -822,6 +822,89 @@ extern "C" long annhip_query_on(annhip_index *ix, annhip_workspace *ws, void *hi
   return query_impl(ix, ws ? *ws : ix->ws, (hipStream_t)hip_stream, Q, y_dev, alias, mode, ids_dev, dists_dev);
 }
 
+// ----------------------------------------------------------------------------- host-side streaming
+// query() hands over host buffers on every call (ann.h:61-62) and returns host buffers: upload, compute and download
+// are serialised and each call ends in a device synchronisation.  A stream of independent host-resident batches does
+// not need that: each of `lanes` in-flight batches has pinned staging buffers, a workspace and a HIP stream, so the
+// upload of batch i+1 and the download of batch i-1 run beside the kernels of batch i.
+struct StreamLane {
+  hipStream_t stream = NULL;
+  annhip_workspace ws;
+  FT *y_pin = NULL, *y_dev = NULL, *d_dev = NULL, *d_pin = NULL;
+  size_t *i_dev = NULL, *i_pin = NULL;
+  hipEvent_t done = NULL;
+  long ticket = -1;  // -1: free
+  size_t ycnt = 0;
+};
+struct annhip_stream {
+  annhip_index *ix;
+  size_t max_ycnt;
+  std::vector<StreamLane> lanes;
+  long next_ticket = 0;
+};
+
+extern "C" annhip_stream *annhip_stream_open(annhip_index *ix, size_t max_ycnt, int lanes) {
+  if (lanes < 1 || lanes > 16 || !max_ycnt) die("annhip_stream_open: need 1..16 lanes and max_ycnt > 0");
+  annhip_stream *st = new annhip_stream();
+  st->ix = ix, st->max_ycnt = max_ycnt;
+  st->lanes.resize(lanes);
+  for (StreamLane &L : st->lanes) {
+    HIPCHECK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+    HIPCHECK(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+    HIPCHECK(hipHostMalloc((void **)&L.y_pin, sizeof(FT) * max_ycnt * ix->d, hipHostMallocDefault));
+    HIPCHECK(hipHostMalloc((void **)&L.d_pin, sizeof(FT) * max_ycnt * ix->k, hipHostMallocDefault));
+    HIPCHECK(hipHostMalloc((void **)&L.i_pin, sizeof(size_t) * max_ycnt * ix->k, hipHostMallocDefault));
+    L.y_dev = dev_alloc<FT>(max_ycnt * ix->d);
+    L.d_dev = dev_alloc<FT>(max_ycnt * ix->k);
+    L.i_dev = dev_alloc<size_t>(max_ycnt * ix->k);
+  }
+  return st;
+}
+
+extern "C" long annhip_stream_submit(annhip_stream *st, size_t ycnt, const ftype *y_host, int alias) {
+  if (ycnt > st->max_ycnt) die("annhip_stream_submit: batch larger than max_ycnt");
+  StreamLane &L = st->lanes[st->next_ticket % (long)st->lanes.size()];
+  if (L.ticket >= 0) return -1;  // every lane is in flight: collect the oldest ticket first
+  annhip_index *ix = st->ix;
+  memcpy(L.y_pin, y_host, sizeof(FT) * ycnt * ix->d);  // the caller's buffer is free again when submit returns
+  HIPCHECK(hipMemcpyAsync(L.y_dev, L.y_pin, sizeof(FT) * ycnt * ix->d, hipMemcpyHostToDevice, L.stream));
+  query_impl(ix, L.ws, L.stream, ycnt, reinterpret_cast<const ftype *>(L.y_dev), alias, 0, L.i_dev,
+             reinterpret_cast<ftype *>(L.d_dev));
+  HIPCHECK(hipMemcpyAsync(L.i_pin, L.i_dev, sizeof(size_t) * ycnt * ix->k, hipMemcpyDeviceToHost, L.stream));
+  HIPCHECK(hipMemcpyAsync(L.d_pin, L.d_dev, sizeof(FT) * ycnt * ix->k, hipMemcpyDeviceToHost, L.stream));
+  HIPCHECK(hipEventRecord(L.done, L.stream));
+  L.ticket = st->next_ticket, L.ycnt = ycnt;
+  return st->next_ticket++;
+}
+
+extern "C" int annhip_stream_collect(annhip_stream *st, long ticket, size_t *ids_host, ftype *dists_host) {
+  if (ticket < 0) return -1;
+  StreamLane &L = st->lanes[ticket % (long)st->lanes.size()];
+  if (L.ticket != ticket) return -1;  // unknown or already collected
+  HIPCHECK(hipEventSynchronize(L.done));
+  memcpy(ids_host, L.i_pin, sizeof(size_t) * L.ycnt * st->ix->k);
+  if (dists_host) memcpy(dists_host, L.d_pin, sizeof(FT) * L.ycnt * st->ix->k);
+  L.ticket = -1;
+  return 0;
+}
+
+extern "C" void annhip_stream_close(annhip_stream *st) {
+  if (!st) return;
+  for (StreamLane &L : st->lanes) {
+    HIPCHECK(hipStreamSynchronize(L.stream));
+    L.ws.release();
+    HIPCHECK(hipHostFree(L.y_pin));
+    HIPCHECK(hipHostFree(L.d_pin));
+    HIPCHECK(hipHostFree(L.i_pin));
+    HIPCHECK(hipFree(L.y_dev));
+    HIPCHECK(hipFree(L.d_dev));
+    HIPCHECK(hipFree(L.i_dev));
+    (void)hipEventDestroy(L.done);
+    (void)hipStreamDestroy(L.stream);
+  }
+  delete st;
+}
+
 // ----------------------------------------------------------------------------- staged API
 extern "C" void annhip_codes(annhip_index *ix, size_t Q, const ftype *y_dev, uint32_t *codes_dev) {
   launch_codes(make_params(ix), Q, reinterpret_cast<const FT *>(y_dev), codes_dev, ix->stream);

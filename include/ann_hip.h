@@ -75,6 +75,18 @@ void annhip_workspace_destroy(annhip_workspace *ws);
 long annhip_query_on(annhip_index *ix, annhip_workspace *ws, void *hip_stream, size_t ycnt, const ftype *y_dev,
                      int alias, int mode, size_t *ids_dev, ftype *dists_dev);
 
+/* Host-resident batches, pipelined: `lanes` batches may be in flight, each with pinned staging buffers, a workspace
+ * and a HIP stream, so uploads, kernels and downloads of consecutive batches overlap (query_gpu serialises them and
+ * synchronises on every call).  submit copies y_host (ftype[ycnt][d], ycnt <= max_ycnt) and returns a ticket >= 0, or
+ * -1 when every lane is in flight (collect the oldest ticket first).  collect waits for that batch and copies
+ * size_t[ycnt][k] ids and ftype[ycnt][k] squared distances (may be NULL) out; returns 0, or -1 for an unknown ticket.
+ * alias != 0 as in annhip_query.  One host thread drives a stream object. */
+typedef struct annhip_stream annhip_stream;
+annhip_stream *annhip_stream_open(annhip_index *ix, size_t max_ycnt, int lanes);
+long annhip_stream_submit(annhip_stream *st, size_t ycnt, const ftype *y_host, int alias);
+int annhip_stream_collect(annhip_stream *st, long ticket, size_t *ids_host, ftype *dists_host);
+void annhip_stream_close(annhip_stream *st);
+
 /* ---- staged query, for point-sharded multi-GPU hosts -------------------------------------------- */
 /* 1. hash codes of the whole batch: codes_dev u32[ycnt*tries], layout [q*tries+t] (alg.c:462-492).     */
 void annhip_codes(annhip_index *ix, size_t ycnt, const ftype *y_dev, uint32_t *codes_dev);

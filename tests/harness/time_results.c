@@ -4,9 +4,10 @@
  * These are the PCIe-inclusive numbers (y goes up and ids/distances come back through host memory on every
  * call); bench.py reports the HBM-resident rate.                                                          */
 #include "harness_common.h"
+#include "ann_hip.h"
 
 int main(int argc, char **argv) {
-  opts_t o = parse_opts(argc, argv, "n:k:d:t:o:y:b:s:a:r:S:hzvc", 10);
+  opts_t o = parse_opts(argc, argv, "n:k:d:t:o:y:b:s:a:r:S:P:hzvc", 10);
   srandom(o.seed);
   if (!o.use_cpu) gpu_init();
   ftype *points = malloc(sizeof(ftype) * o.n * o.d), *dists;
@@ -45,6 +46,34 @@ int main(int argc, char **argv) {
       double avg = o.reps > 1 ? tg / warm : first;
       printf("Average time for query (on GPU, host buffers): %gs  => %.0f queries/s  (first call %gs)\n", avg,
              o.ycnt / avg, first);
+    }
+    if (!o.use_cpu && o.lanes > 0) {
+      /* the same kind of batches through the pipelined host API: uploads, kernels and downloads overlap */
+      annhip_index *ix = annhip_index_create(&save, points, 0, 0, save.n);
+      annhip_stream *st = annhip_stream_open(ix, o.ycnt, o.lanes);
+      size_t nb = o.reps * 4 + (size_t)o.lanes;
+      ftype *ys = malloc(sizeof(ftype) * o.ycnt * o.d * (size_t)o.lanes);
+      size_t *ids = malloc(sizeof(size_t) * o.ycnt * o.k);
+      ftype *dd = malloc(sizeof(ftype) * o.ycnt * o.k);
+      for (int l = 0; l < o.lanes; l++) oracle_gen_rand(o.ycnt * o.d, ys + (size_t)l * o.ycnt * o.d);
+      long head = 0;
+      double tp = 0;
+      for (size_t b = 0; b < nb; b++) {
+        if (b == (size_t)o.lanes) tp = now_s();  /* timed once the pipeline is full */
+        long t = annhip_stream_submit(st, o.ycnt, ys + (b % o.lanes) * o.ycnt * o.d, 0);
+        if (t < 0) {
+          annhip_stream_collect(st, head++, ids, dd);
+          t = annhip_stream_submit(st, o.ycnt, ys + (b % o.lanes) * o.ycnt * o.d, 0);
+        }
+      }
+      while (head < (long)nb) annhip_stream_collect(st, head++, ids, dd);
+      tp = now_s() - tp;
+      double per = tp / (nb - o.lanes);
+      printf("Average time for query (on GPU, host buffers, %d-lane pipeline): %gs  => %.0f queries/s\n", o.lanes, per,
+             o.ycnt / per);
+      annhip_stream_close(st);
+      annhip_index_destroy(ix);
+      free(ys), free(ids), free(dd);
     }
     printf("Average time for query (on CPU, oracle, 1 of %ld cores): %gs  => %.0f queries/s\n",
            sysconf(_SC_NPROCESSORS_ONLN), tc / cpu_reps, o.ycnt / (tc / cpu_reps));

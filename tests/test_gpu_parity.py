@@ -150,3 +150,23 @@ def test_overlapped_batches_on_two_streams_match():
         assert torch.equal(wi, gi) and torch.equal(wd.view(torch.int32), gd.view(torch.int32))
     _check(got[0][0].cpu().numpy().astype(np.uint64), got[0][1].cpu().numpy(), g["query_ids"], g["query_dists"], "overlapped")
     ix.close()
+
+
+def test_host_stream_pipeline_matches_query():
+    """annhip_stream_*: host batches through the pinned, multi-lane pipeline give query()'s answers, in order."""
+    import torch
+    g = load_golden("pow2_d64_f32")
+    save = A.Save.from_dict("f32", g["save"])
+    pts = np.ascontiguousarray(g["points"])
+    ix = A.Index.from_save(save, pts)
+    rng = np.random.default_rng(5)
+    batches = [g["y"]] + [rng.standard_normal((n, pts.shape[1])).astype(np.float32) for n in (64, 1, 33, 64, 17, 64)]
+    want = [A.query(save, pts, b) for b in batches]
+    hs = ix.host_stream(max_ycnt=64, lanes=3)
+    got = list(hs.map(batches))
+    hs.close()
+    for (wi, wd), (gi, gd) in zip(want, got):
+        assert np.array_equal(wi, gi) and bits_equal(wd, gd)
+    _check(got[0][0], got[0][1], g["query_ids"], g["query_dists"], "host stream")
+    ix.close()
+    A._lib.load("f32").annhip_cache_clear()
