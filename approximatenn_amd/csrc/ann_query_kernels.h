@@ -623,7 +623,7 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
 // stage1_select with alias = 1 (self excluded); nv_tot is exact here (valid slots minus the member itself).
 // Host-side conditions (else the per-point kernel is used): power-of-two d, pm members' selection state + one tile
 // fit LDS.
-#define ANN_BK_TILE_ROWS 64
+#define ANN_BK_TILE_ROWS 32  // measured at cfg3: 16 -> 0.89 s, 32 -> 0.92 s, 64 -> 1.17 s, 128 -> 1.54 s of precomp (occupancy beats fewer barriers)
 #define ANN_BK_MAX_RUNS 64
 template <int D>
 __global__ __launch_bounds__(256) void stage1_bucket_kernel(QParams P, int K1, int cap, u32 list_cap,
