@@ -140,6 +140,13 @@ static T *dev_alloc(size_t count) {
   return (T *)p;
 }
 
+// size limits with test hooks: ANN_HIP_LDS_ROW_MAX (bytes of one exact-path row kept in LDS; longer rows run the
+// network in HBM) and ANN_HIP_EXACT_BYTES (workspace budget of the exact path; larger needs are chunked / host-driven)
+static size_t env_bytes(const char *name, size_t dflt) {
+  const char *e = getenv(name);
+  return e && atoll(e) > 0 ? (size_t)atoll(e) : dflt;
+}
+
 static unsigned grid_for(size_t work, unsigned block, unsigned cap = 1u << 20) {
   size_t g = (work + block - 1) / block;
   if (g < 1) g = 1;
@@ -628,7 +635,7 @@ static void launch_exact_select(u32 L, u32 len, u32 in_stride, int k, size_t nq,
   if (block < 64) block = 64;
   const size_t smem = (size_t)len * (sizeof(FT) + sizeof(u32));
   const unsigned grid = live_rows ? (unsigned)std::min<size_t>(nq, 512) : (unsigned)nq;
-  if (smem <= 150 * 1024) {  // the whole row in LDS (one CU has 160 KB); longer rows sort in place in HBM
+  if (smem <= env_bytes("ANN_HIP_LDS_ROW_MAX", 150 * 1024)) {  // the whole row in LDS (a CU has 160 KB); longer rows sort in place in HBM
     allow_lds(exact_select_kernel<true>, smem);
     hipLaunchKernelGGL(exact_select_kernel<true>, dim3(grid), dim3(block), smem, s, L, len, in_stride, k,
                        ids, dist, qidx, xbase, out_i, out_d, ostride, ooff, live_rows, (u32)nq, out64);
@@ -653,7 +660,7 @@ static long finalize_and_fallback(annhip_index *ix, const QParams &P, size_t Q, 
   u32 nflag = 0;
   u32 *fl = (u32 *)flist.need(sizeof(u32) * Q);
   const size_t row_bytes = (size_t)P.Lc1 * (sizeof(FT) + sizeof(u32));
-  size_t chunk = ((size_t)1 << 30) / (row_bytes ? row_bytes : 1);
+  size_t chunk = env_bytes("ANN_HIP_EXACT_BYTES", (size_t)1 << 30) / (row_bytes ? row_bytes : 1);
   if (chunk < 1) chunk = 1;
   if (mode == 0) {
     zero_u32_kernel<<<1, 1, 0, s>>>(d_fcount);
@@ -737,7 +744,7 @@ static long query_impl(annhip_index *ix, annhip_workspace &ws, hipStream_t s, si
     // keeps the workgroup's registers/LDS occupied through a chain of dependent loads.  So: small batches only.
     const char *fenv = getenv("ANN_HIP_FUSE");  // "0" = never, "1" = whenever possible (A/B switch)
     const bool want = fenv ? atoi(fenv) != 0 : Q <= 2048;
-    if (mode == 0 && whole && want && P.Lc2 <= 1024 && Q * xrow <= ((size_t)1 << 30)) {
+    if (mode == 0 && whole && want && P.Lc2 <= 1024 && Q * xrow <= env_bytes("ANN_HIP_EXACT_BYTES", (size_t)1 << 30)) {
       FT *out_d = dists_dev ? reinterpret_cast<FT *>(dists_dev) : (FT *)ws.out_d.need(sizeof(FT) * Q * k);
       u32 *fl = (u32 *)ws.flist.need(sizeof(u32) * Q);
       u32 *nvo = (u32 *)ws.nvo.need(sizeof(u32) * Q);

@@ -142,3 +142,32 @@ def test_residency_cache_detects_changed_content():
     got = A.query(save, pts, g["y"])
     assert np.array_equal(got[0], want[0]) and bits_equal(got[1], want[1])
     A._lib.load("f32").annhip_cache_clear()
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_network_in_hbm_and_chunked_host_driven_exact_path(prec, monkeypatch):
+    """Paths that only very large shapes reach (full-size cfg5 rows do not fit LDS; cfg4's Q=100k exceeds the exact
+    path's workspace budget): force them with the size hooks on a ties-heavy dataset, in both path modes."""
+    orc = O.CpuBackend(prec, "oracle")
+    O.srandom(77)
+    orc.rand_norm_reset()
+    half = orc.gen_rand(600 * 32).reshape(600, 32)
+    pts = np.ascontiguousarray(np.concatenate([half, half]))     # duplicated points: most queries get rejected
+    y = orc.gen_rand(70 * 32).reshape(70, 32)
+    O.srandom(9)
+    o_ids, o_d, o_save = orc.precomp(pts, 6, 4)
+    want = orc.query(o_save, pts, y)
+    monkeypatch.setenv("ANN_HIP_LDS_ROW_MAX", "64")              # every exact-path row sorts in HBM
+    monkeypatch.setenv("ANN_HIP_EXACT_BYTES", "20000")           # a few rows per chunk, host-driven
+    for exact in (False, True):
+        if exact:
+            monkeypatch.setenv("ANN_HIP_EXACT", "1")
+        O.srandom(9)
+        ids, dd, save = A.precomp(pts, 6, 4)
+        try:
+            assert np.array_equal(ids, o_ids) and bits_equal(dd, o_d)
+            got = A.query(save, pts, y)
+            assert np.array_equal(got[0], want[0]) and bits_equal(got[1], want[1])
+        finally:
+            A._lib.load(prec).annhip_cache_clear()
+            save.free()
