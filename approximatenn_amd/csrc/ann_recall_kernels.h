@@ -75,9 +75,8 @@ __global__ __launch_bounds__(256) void recall_scan_kernel(const FT *__restrict__
 #pragma unroll
       for (int c = 0; c < L::C; c++) a[c] = yp[c * L::LPR];
       const FT *gq = gdist + (size_t)q * k;
-      const FT far = gq[k - 1] < ft_inf() ? gq[k - 1] : ft_inf();
-      FT gfar = far;
-      for (int j = 0; j < k; j++) gfar = gq[j] > gfar ? gq[j] : gfar;  // guesses need not be sorted
+      FT gfar = gq[0];
+      for (int j = 1; j < k; j++) gfar = gq[j] > gfar ? gq[j] : gfar;  // guesses need not be sorted
       for (u32 r0 = 0; r0 < rows; r0 += L::RPW) {
         const u32 r = r0 + g;
         const bool act = r < rows && !(self && row0 + r == (u32)q);
