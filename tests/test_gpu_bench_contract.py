@@ -30,3 +30,20 @@ def test_bench_line_contract():
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] == 1 and c["value"] > 0
     assert c["parity_on_sample"] == {"ids_bit_exact": True, "dists_bit_exact": True}
+
+
+def test_bench_multi_rank_branch_two_ranks_sharing_the_gpu():
+    """The --gpus N branch (row sharding, staged calls, collectives, max-over-ranks timing) with 2 ranks on this box's
+    single GPU and gloo collectives (ANN_BENCH_SHARED_GPU=1): the path the driver runs on a multi-GPU node over RCCL."""
+    env = dict(os.environ, ANN_BENCH_SHARED_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29633", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--points", "200000", "--queries", "1000",
+           "--steps", "2", "--warmup", "1"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["points_sharding"] == "rows/2" and "Q=2000/step" in d["config"]["workload"]
+    assert "cpu_baseline" not in d          # rank 0 at N=1 only
