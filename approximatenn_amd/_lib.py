@@ -28,6 +28,12 @@ def build(verbose=False):
     subprocess.check_call(cmd)
 
 
+def reload_env():
+    """Make every loaded library re-read the ANN_HIP_* switches (they are cached after the first call)."""
+    for lib in _libs.values():
+        lib.annhip_reload_env()
+
+
 def lib_path(prec):
     return os.path.join(CSRC, "libapproxnn_hip_%s.so" % prec)
 
@@ -91,6 +97,12 @@ def load(prec="f32"):
     lib.annhip_stats.argtypes = [vp, C.POINTER(C.c_double * 8), C.c_int]
     lib.annhip_stage_ms.argtypes = [vp, C.POINTER(C.c_double * 6)]
     lib.annhip_cache_clear.argtypes = []
+    lib.annhip_cache_drop.argtypes = [C.POINTER(SaveT)]
+    lib.annhip_cache_size.restype = sz
+    lib.annhip_cache_size.argtypes = []
+    lib.annhip_reload_env.argtypes = []
+    lib.annhip_synth_randnorm.argtypes = [sz, vp]
+    lib.annhip_synth_reset.argtypes = []
     lib.gpu_init.argtypes = []
     lib.gpu_cleanup.argtypes = []
     lib.register_cleanup.argtypes = [C.CFUNCTYPE(None)]
@@ -108,5 +120,7 @@ EXPORTED = ["gpu_init", "gpu_cleanup", "register_cleanup", "query_gpu", "precomp
             "annhip_index_export", "annhip_index_reshard", "annhip_save_write", "annhip_save_read", "annhip_precomp_index", "annhip_query", "annhip_workspace_create", "annhip_workspace_destroy", "annhip_query_on", "annhip_stream_open", "annhip_stream_submit", "annhip_stream_collect", "annhip_stream_close",
             "annhip_codes", "annhip_stage1_local",
             "annhip_merge_candidates", "annhip_stage1_finalize", "annhip_stage1_rows", "annhip_stage2_rows", "annhip_exact_select",
-            "annhip_widen_ids", "annhip_recall_ranks", "annhip_profile", "annhip_stats", "annhip_stage_ms"]
+            "annhip_widen_ids", "annhip_recall_ranks", "annhip_profile", "annhip_stats", "annhip_stage_ms",
+            "annhip_cache_clear", "annhip_cache_drop", "annhip_cache_size", "annhip_reload_env",
+            "annhip_synth_randnorm", "annhip_synth_reset"]
 DISPATCH_EXPORTED = ["precomp", "query", "free_save"]

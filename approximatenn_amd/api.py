@@ -157,6 +157,17 @@ def query(save, points, y, want_dists=True):
     return ids, _take(dptr, ycnt * k, cft, _ft(prec)).reshape(ycnt, k)
 
 
+def synth_randnorm(count, prec="f32", reset=False):
+    """annhip_synth_randnorm: `count` N(0,1) values from the caller's libc random() stream, exactly the values the
+    reference's drivers generate (time_results.c:10-13, randNorm.c:9-21).  Seed with libc srandom() first."""
+    lib = _lib.load(prec)
+    if reset:
+        lib.annhip_synth_reset()
+    out = np.empty(int(count), dtype=_ft(prec))
+    lib.annhip_synth_randnorm(int(count), out.ctypes.data)
+    return out
+
+
 class HostStream:
     """annhip_stream_*: numpy batches in, numpy results out, up to `lanes` batches in flight.
 

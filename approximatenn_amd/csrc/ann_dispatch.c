@@ -8,6 +8,7 @@
 
 #include "algg.h"
 #include "ann.h"
+#include "ann_hip.h"
 
 static void no_cpu_path(const char *what) {
   fprintf(stderr, "%s: use_cpu != 0 requested, but the CPU path (algc.c) is not part of the HIP backend\n", what);
@@ -28,6 +29,7 @@ size_t *precomp(size_t n, size_t k, size_t d, const ftype *points, int tries, si
 
 /* every field is plain malloc memory (ann.c:25-34) */
 void free_save(save_t *save) {
+  annhip_cache_drop(save); /* the resident copy of this index goes with it */
   for (int t = 0; t < save->tries; t++) free(save->which_par[t]);
   free(save->which_par);
   free(save->par_maxes);

@@ -57,6 +57,52 @@ struct RandGuard {
   }
 };
 
+// ----------------------------------------------------------------------------- environment switches
+// A/B and test hooks ("Environment switches"), read ONCE -- at the first entry into the library and again
+// whenever annhip_reload_env() is called -- never on the per-batch host path.
+struct EnvCfg {
+  bool loaded = false;
+  bool exact = false, slot_scan = false, point_precomp = false, all_tries = false;
+  int fuse = -1;      // ANN_HIP_FUSE: -1 unset, 0 never, 1 whenever possible
+  int s1_waves = 0;   // ANN_HIP_S1_WAVES: 0 unset
+  int s1_persist = -1;  // ANN_HIP_S1_PERSIST: -1 unset (auto), 0 one workgroup per query, 1 persistent multi-query workgroups
+  size_t lds_row_max = 150 * 1024, exact_bytes = (size_t)1 << 30;
+  size_t exact_rows = 0;  // ANN_HIP_EXACT_ROWS: rows of the device-driven exact workspace (0 = auto)
+  int cache_mode = 0;  // ANN_HIP_CACHE: 0 sampled fingerprint (default), 1 strict (full content hash), 2 off
+};
+static EnvCfg g_env;
+static size_t env_size(const char *name, size_t dflt) {
+  const char *e = getenv(name);
+  return e && atoll(e) > 0 ? (size_t)atoll(e) : dflt;
+}
+static int env_int(const char *name, int dflt) {
+  const char *e = getenv(name);
+  return e && *e ? atoi(e) : dflt;
+}
+static void load_env() {
+  EnvCfg c;
+  c.loaded = true;
+  c.exact = getenv("ANN_HIP_EXACT") != NULL;
+  c.slot_scan = getenv("ANN_HIP_SLOT_SCAN") != NULL;
+  c.point_precomp = getenv("ANN_HIP_POINT_PRECOMP") != NULL;
+  c.all_tries = getenv("ANN_HIP_PRECOMP_ALL_TRIES") != NULL;
+  c.fuse = env_int("ANN_HIP_FUSE", -1);
+  c.s1_waves = env_int("ANN_HIP_S1_WAVES", 0);
+  if (c.s1_waves < 1 || c.s1_waves > 4) c.s1_waves = 0;
+  c.s1_persist = env_int("ANN_HIP_S1_PERSIST", -1);
+  c.lds_row_max = env_size("ANN_HIP_LDS_ROW_MAX", 150 * 1024);
+  c.exact_bytes = env_size("ANN_HIP_EXACT_BYTES", (size_t)1 << 30);
+  c.exact_rows = env_size("ANN_HIP_EXACT_ROWS", 0);
+  const char *cm = getenv("ANN_HIP_CACHE");
+  c.cache_mode = !cm ? 0 : !strcmp(cm, "strict") ? 1 : !strcmp(cm, "off") ? 2 : 0;
+  g_env = c;
+}
+static inline const EnvCfg &env() {
+  if (!g_env.loaded) load_env();
+  return g_env;
+}
+extern "C" void annhip_reload_env(void) { load_env(); }
+
 // ----------------------------------------------------------------------------- device lifecycle
 static bool g_init = false;
 struct CleanupNode {
@@ -138,13 +184,6 @@ static T *dev_alloc(size_t count) {
   void *p = NULL;
   HIPCHECK(hipMalloc(&p, (count ? count : 1) * sizeof(T)));
   return (T *)p;
-}
-
-// size limits with test hooks: ANN_HIP_LDS_ROW_MAX (bytes of one exact-path row kept in LDS; longer rows run the
-// network in HBM) and ANN_HIP_EXACT_BYTES (workspace budget of the exact path; larger needs are chunked / host-driven)
-static size_t env_bytes(const char *name, size_t dflt) {
-  const char *e = getenv(name);
-  return e && atoll(e) > 0 ? (size_t)atoll(e) : dflt;
 }
 
 static unsigned grid_for(size_t work, unsigned block, unsigned cap = 1u << 20) {
@@ -260,7 +299,7 @@ static void build_segments(annhip_index *ix) {
   u32 nbad = 0;
   HIPCHECK(hipMemcpy(&nbad, bad, sizeof(u32), hipMemcpyDeviceToHost));
   HIPCHECK(hipFree(bad));
-  ix->use_seg = nbad == 0 && !getenv("ANN_HIP_SLOT_SCAN");
+  ix->use_seg = nbad == 0 && !env().slot_scan;
 }
 
 static void check_limits(size_t n, size_t k, size_t d, size_t ds, int T) {
@@ -478,8 +517,7 @@ static int stage1_waves(u32 P1, double own_frac) {
   if (w < 1) w = 1;
   if (w > 4) w = 4;
   if (own_frac < 0.2) w = 1;
-  const char *e = getenv("ANN_HIP_S1_WAVES");
-  if (e && atoi(e) >= 1 && atoi(e) <= 4) w = atoi(e);  // measured at cfg3: 4 = 2 (1.19 ms) < 8 (1.21) < 1 (1.28)
+  if (env().s1_waves) w = env().s1_waves;  // ANN_HIP_S1_WAVES; measured at cfg3: 4 = 2 (1.19 ms) < 8 (1.21) < 1 (1.28)
   return w;
 }
 static int stage1_cap(int W, int K1) {
@@ -573,7 +611,7 @@ static void launch_bucket_d(const QParams &P, size_t nbuckets, int W, int K1, in
 // bucket-centric stage 1 of precomp: returns false when the shape does not fit (caller uses the per-point kernel)
 static bool launch_stage1_bucket(const QParams &P, const TryInfo &one, size_t nbuckets, FT *cand_d, u32 *cand_i, u32 *nvt,
                                  u32 *nvo, hipStream_t s) {
-  if (!d_is_fast(P.d) || getenv("ANN_HIP_POINT_PRECOMP")) return false;
+  if (!d_is_fast(P.d) || env().point_precomp) return false;
   const int K1 = P.k + 1, W = 4;
   int cap = K1 + 2 * 16;  // room for one pass of up to RPW = 16 keys after a shrink
   cap = (cap + 7) & ~7;
@@ -635,7 +673,7 @@ static void launch_exact_select(u32 L, u32 len, u32 in_stride, int k, size_t nq,
   if (block < 64) block = 64;
   const size_t smem = (size_t)len * (sizeof(FT) + sizeof(u32));
   const unsigned grid = live_rows ? (unsigned)std::min<size_t>(nq, 512) : (unsigned)nq;
-  if (smem <= env_bytes("ANN_HIP_LDS_ROW_MAX", 150 * 1024)) {  // the whole row in LDS (a CU has 160 KB); longer rows sort in place in HBM
+  if (smem <= env().lds_row_max) {  // the whole row in LDS (a CU has 160 KB); longer rows sort in place in HBM
     allow_lds(exact_select_kernel<true>, smem);
     hipLaunchKernelGGL(exact_select_kernel<true>, dim3(grid), dim3(block), smem, s, L, len, in_stride, k,
                        ids, dist, qidx, xbase, out_i, out_d, ostride, ooff, live_rows, (u32)nq, out64);
@@ -660,7 +698,7 @@ static long finalize_and_fallback(annhip_index *ix, const QParams &P, size_t Q, 
   u32 nflag = 0;
   u32 *fl = (u32 *)flist.need(sizeof(u32) * Q);
   const size_t row_bytes = (size_t)P.Lc1 * (sizeof(FT) + sizeof(u32));
-  size_t chunk = env_bytes("ANN_HIP_EXACT_BYTES", (size_t)1 << 30) / (row_bytes ? row_bytes : 1);
+  size_t chunk = env().exact_bytes / (row_bytes ? row_bytes : 1);
   if (chunk < 1) chunk = 1;
   if (mode == 0) {
     zero_u32_kernel<<<1, 1, 0, s>>>(d_fcount);
@@ -720,7 +758,7 @@ static long query_impl(annhip_index *ix, annhip_workspace &ws, hipStream_t s, si
   if (!ws.d_fcount) ws.d_fcount = dev_alloc<u32>(4);
   const FT *y = reinterpret_cast<const FT *>(y_dev);
   const int k = P.k, K1 = k + 1;
-  if (getenv("ANN_HIP_EXACT")) mode = 1;
+  if (env().exact) mode = 1;
   if ((u32)k > P.P1) mode = 1;
   std::vector<hipEvent_t> marks_store, *marks = ix->profile ? &marks_store : NULL;
   seg_mark(ix, marks, s);
@@ -742,9 +780,8 @@ static long query_impl(annhip_index *ix, annhip_workspace &ws, hipStream_t s, si
     const bool whole = ix->lo == 0 && ix->hi == ix->n;
     // Measured: +5 % at Q = 1k (launch-bound), neutral at cfg3 (Q = 10k, d = 128), -6 % at Q = 10k, d = 64 -- the tail
     // keeps the workgroup's registers/LDS occupied through a chain of dependent loads.  So: small batches only.
-    const char *fenv = getenv("ANN_HIP_FUSE");  // "0" = never, "1" = whenever possible (A/B switch)
-    const bool want = fenv ? atoi(fenv) != 0 : Q <= 2048;
-    if (mode == 0 && whole && want && P.Lc2 <= 1024 && Q * xrow <= env_bytes("ANN_HIP_EXACT_BYTES", (size_t)1 << 30)) {
+    const bool want = env().fuse >= 0 ? env().fuse != 0 : Q <= 2048;  // ANN_HIP_FUSE: 0 = never, 1 = whenever possible
+    if (mode == 0 && whole && want && P.Lc2 <= 1024 && Q * xrow <= env().exact_bytes) {
       FT *out_d = dists_dev ? reinterpret_cast<FT *>(dists_dev) : (FT *)ws.out_d.need(sizeof(FT) * Q * k);
       u32 *fl = (u32 *)ws.flist.need(sizeof(u32) * Q);
       u32 *nvo = (u32 *)ws.nvo.need(sizeof(u32) * Q);
@@ -933,7 +970,7 @@ extern "C" long annhip_stage1_finalize(annhip_index *ix, size_t Q, const ftype *
   const QParams P = make_params(ix);
   hipStream_t s = ix->stream;
   u32 nflag = 0;
-  if ((u32)P.k > P.P1 || getenv("ANN_HIP_EXACT")) {  // everything through the exact path
+  if ((u32)P.k > P.P1 || env().exact) {  // everything through the exact path
     std::vector<u32> all(Q);
     for (size_t i = 0; i < Q; i++) all[i] = (u32)i;
     HIPCHECK(hipMemcpyAsync(flagged_dev, all.data(), sizeof(u32) * Q, hipMemcpyHostToDevice, s));
@@ -1166,7 +1203,7 @@ extern "C" annhip_index *annhip_precomp_index(size_t n, size_t k, size_t d, cons
   }
   RandGuard keep_callers_stream;
   gpu_init();
-  const bool exact_all = getenv("ANN_HIP_EXACT") != NULL;
+  const bool exact_all = env().exact;
   hipStream_t s = 0;
 
   annhip_index *ix = new annhip_index();
@@ -1227,9 +1264,17 @@ extern "C" annhip_index *annhip_precomp_index(size_t n, size_t k, size_t d, cons
   HIPCHECK(hipFree(centred));
 
   // second_half per try (alg.c:245-290): bucket table, then each point's candidates -> its k best
+  // The merge over tries (det_results, alg.c:308-312) sorts a row of W = k*T entries, i.e. only its first
+  // ann_need_len(W, k) columns are ever read: a try whose column block starts at or beyond that length
+  // contributes its bucket table (query() probes every table) but its distance pass would be computed and never
+  // looked at -- tries 7..9 of 10 at cfg3, 6..9 at cfg5.  Those tries skip the pass, and the merged rows are stored
+  // with the shorter stride Wn (cfg5: 61 GB instead of 120 GB).  ANN_HIP_PRECOMP_ALL_TRIES=1 runs every pass (A/B).
   const size_t nb = (size_t)1 << ds, W = k * (size_t)T;
-  u32 *merged_i = dev_alloc<u32>(n * W);
-  FT *merged_d = dev_alloc<FT>(n * W);
+  const size_t need_W = ann_need_len(W, k);
+  const int tries_scored = env().all_tries ? T : (int)std::min<size_t>((size_t)T, (need_W + k - 1) / k);
+  const size_t Wn = (size_t)tries_scored * k;
+  u32 *merged_i = dev_alloc<u32>(n * Wn);
+  FT *merged_d = dev_alloc<FT>(n * Wn);
   u32 *cnt = dev_alloc<u32>(nb), *cursor = dev_alloc<u32>(nb), *d_max_cnt = dev_alloc<u32>(1);
   ix->h_tries.resize(T);
   ix->d_tabs.resize(T);
@@ -1275,6 +1320,11 @@ extern "C" annhip_index *annhip_precomp_index(size_t n, size_t k, size_t d, cons
     P.n = (u32)n, P.lo = 0, P.hi = (u32)n, P.d = (int)d, P.k = (int)k, P.T = 1, P.ds = (int)ds;
     P.L1 = one.end, P.P1 = 1u << ann_lg(P.L1), P.Lc1 = (u32)ann_need_len(P.L1, k);
     P.L2 = P.Lc2 = 0;
+    if (t >= tries_scored) {  // table, pm and segments are kept; nothing reads this try's merged columns
+      HIPCHECK(hipStreamSynchronize(s));
+      HIPCHECK(hipFree(codes[t]));
+      continue;
+    }
     int mode = (exact_all || (u32)k > P.P1) ? 1 : 0;
     FT *cd = NULL;
     u32 *ci = NULL, *nv = NULL;
@@ -1284,9 +1334,9 @@ extern "C" annhip_index *annhip_precomp_index(size_t n, size_t k, size_t d, cons
       nv = (u32 *)nvt.need(sizeof(u32) * n);
       u32 *no = (u32 *)nvo.need(sizeof(u32) * n);
       if (!launch_stage1_bucket(P, one, nb, cd, ci, nv, no, s))
-        launch_stage1(NULL, P, n, pts, 1, codes[t], cd, ci, nv, no, s, std::vector<TryInfo>(1, one), !getenv("ANN_HIP_SLOT_SCAN"));
+        launch_stage1(NULL, P, n, pts, 1, codes[t], cd, ci, nv, no, s, std::vector<TryInfo>(1, one), !env().slot_scan);
     }
-    finalize_and_fallback(NULL, P, n, pts, 1, codes[t], mode, cd, ci, nv, merged_i, merged_d, (int)W, (int)(t * k),
+    finalize_and_fallback(NULL, P, n, pts, 1, codes[t], mode, cd, ci, nv, merged_i, merged_d, (int)Wn, (int)(t * k),
                           flist, xids, xd, ix->ws.d_fcount, NULL, NULL, false, s);
     HIPCHECK(hipStreamSynchronize(s));
     HIPCHECK(hipFree(codes[t]));
@@ -1300,7 +1350,7 @@ extern "C" annhip_index *annhip_precomp_index(size_t n, size_t k, size_t d, cons
     HIPCHECK(hipMemcpy(&nbad, d_bad, sizeof(u32), hipMemcpyDeviceToHost));
     HIPCHECK(hipFree(d_bad));
     if (nbad) die("internal error: a bucket table built by precomp is not in sorted-prefix layout");
-    ix->use_seg = !getenv("ANN_HIP_SLOT_SCAN");
+    ix->use_seg = !env().slot_scan;
   }
   cand_d.release(), cand_i.release(), nvt.release(), nvo.release(), flist.release(), xids.release(), xd.release();
 
@@ -1308,7 +1358,7 @@ extern "C" annhip_index *annhip_precomp_index(size_t n, size_t k, size_t d, cons
   finish_geometry(ix);
   u32 *top_i = dev_alloc<u32>(n * k);
   FT *top_d = dev_alloc<FT>(n * k);
-  launch_exact_select((u32)W, (u32)ann_need_len(W, k), (u32)W, (int)k, n, merged_i, merged_d, NULL, 0, top_i, top_d,
+  launch_exact_select((u32)W, (u32)std::min(need_W, Wn), (u32)Wn, (int)k, n, merged_i, merged_d, NULL, 0, top_i, top_d,
                       (int)k, 0, s);
   HIPCHECK(hipStreamSynchronize(s));
   HIPCHECK(hipFree(merged_i));
@@ -1339,9 +1389,16 @@ extern "C" annhip_index *annhip_precomp_index(size_t n, size_t k, size_t d, cons
 }
 
 // ----------------------------------------------------------------------------- residency cache
-// query() receives host pointers on every call (ann.h:61-62).  Re-uploading a multi-GB point matrix per
-// call would make the path PCIe-bound, so indexes stay resident, keyed by the host pointers and a
-// fingerprint of sampled content; gpu_cleanup() or annhip_cache_clear() drops them.
+// query() receives host pointers on every call (ann.h:61-62) and the reference re-wraps every buffer per call
+// (alg.c:444-445,503-508).  Re-uploading a multi-GB point matrix per call would make the path PCIe-bound, so indexes
+// stay resident, keyed by the host pointers plus a content fingerprint; gpu_cleanup(), annhip_cache_clear() or
+// annhip_cache_drop(save) release them.
+//
+// Contract: the fingerprint covers par_maxes, row_means and bases IN FULL and strided
+// samples (1 024 elements each) of points, graph and every which_par[t].  A caller that edits points / graph /
+// which_par IN PLACE between two query() calls on the same addresses must either call annhip_cache_drop(save) /
+// annhip_cache_clear(), or run with ANN_HIP_CACHE=strict (every call hashes the full content: exact, ~1 s per call
+// at cfg3) or ANN_HIP_CACHE=off (every call uploads, the reference's behaviour).
 struct CacheEntry {
   const save_t *save;
   const ftype *points;
@@ -1352,27 +1409,61 @@ struct CacheEntry {
   annhip_index *ix;
 };
 static std::vector<CacheEntry> g_cache;
+#define ANN_CACHE_SLOTS 4
+#define ANN_FP_SAMPLES 1024
+
+struct FpHash {  // four independent multiply lanes over 64-bit words: a few GB/s per core, order-sensitive
+  u64 h[4] = {0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull};
+  size_t cnt = 0;
+  inline void word(u64 v) {
+    u64 &x = h[cnt++ & 3];
+    x = (x ^ v) * 0xFF51AFD7ED558CCDull;
+    x ^= x >> 29;
+  }
+  void bytes(const void *p, size_t nbytes) {
+    const unsigned char *b = (const unsigned char *)p;
+    size_t i = 0;
+    for (; i + 8 <= nbytes; i += 8) {
+      u64 v;
+      memcpy(&v, b + i, 8);
+      word(v);
+    }
+    if (i < nbytes) {
+      u64 v = 0;
+      memcpy(&v, b + i, nbytes - i);
+      word(v);
+    }
+    word(nbytes);
+  }
+  template <typename T>
+  void sampled(const T *p, size_t count) {  // ANN_FP_SAMPLES strided elements incl. first and last; everything if short
+    if (count <= ANN_FP_SAMPLES) return bytes(p, count * sizeof(T));
+    for (size_t i = 0; i < ANN_FP_SAMPLES; i++) {
+      u64 v = 0;
+      memcpy(&v, &p[(size_t)((unsigned __int128)(count - 1) * i / (ANN_FP_SAMPLES - 1))], sizeof(T));
+      word(v);
+    }
+  }
+  u64 done() const { return (h[0] * 3 + h[1] * 5 + h[2] * 7 + h[3] * 11) ^ (u64)cnt; }
+};
 
 static u64 fingerprint(const save_t *sv, const ftype *points) {
-  u64 h = 1469598103934665603ull;
-  auto mix = [&](u64 v) {
-    h ^= v;
-    h *= 1099511628211ull;
-  };
-  for (int t = 0; t < sv->tries; t++) mix(sv->par_maxes[t]);
-  const size_t np = sv->n * sv->d_long, ng = sv->n * sv->k;
-  for (size_t i = 0; i < 257; i++) {
-    UB b;
-    memcpy(&b, &points[(np - 1) * i / 256], sizeof b);
-    mix(b);
-    mix(sv->graph[(ng - 1) * i / 256]);
+  const bool full = env().cache_mode == 1;
+  const size_t nb = (size_t)1 << sv->d_short;
+  FpHash H;
+  H.bytes(sv->par_maxes, sizeof(size_t) * sv->tries);
+  H.bytes(sv->row_means, sizeof(ftype) * sv->d_long);
+  H.bytes(sv->bases, sizeof(ftype) * (size_t)sv->tries * sv->d_short * sv->d_long);
+  if (full) {
+    H.bytes(points, sizeof(ftype) * sv->n * sv->d_long);
+    H.bytes(sv->graph, sizeof(size_t) * sv->n * sv->k);
+    for (int t = 0; t < sv->tries; t++) H.bytes(sv->which_par[t], sizeof(size_t) * nb * sv->par_maxes[t]);
+  } else {
+    H.sampled(points, sv->n * sv->d_long);
+    H.sampled(sv->graph, sv->n * sv->k);
+    for (int t = 0; t < sv->tries; t++) H.sampled(sv->which_par[t], nb * sv->par_maxes[t]);
   }
-  for (size_t z = 0; z < sv->d_long; z++) {
-    UB b;
-    memcpy(&b, &sv->row_means[z], sizeof b);
-    mix(b);
-  }
-  return h;
+  return H.done();
 }
 
 static void cache_clear() {
@@ -1381,24 +1472,55 @@ static void cache_clear() {
 }
 extern "C" void annhip_cache_clear(void) { cache_clear(); }
 
-static annhip_index *cache_get(const save_t *sv, const ftype *points) {
-  const u64 fp = fingerprint(sv, points);
-  for (size_t i = 0; i < g_cache.size(); i++) {
-    CacheEntry &e = g_cache[i];
-    if (e.save == sv && e.points == points && e.graph == sv->graph && e.n == sv->n && e.k == sv->k &&
-        e.d == sv->d_long && e.T == sv->tries) {
-      if (e.fp == fp) return e.ix;
-      annhip_index_destroy(e.ix);  // same addresses, different content: stale
+// forget every resident index built for this save_t (free_save() of the bundled dispatcher calls it)
+extern "C" void annhip_cache_drop(const save_t *save) {
+  for (size_t i = 0; i < g_cache.size();) {
+    if (g_cache[i].save == save) {
+      annhip_index_destroy(g_cache[i].ix);
       g_cache.erase(g_cache.begin() + i);
-      break;
+    } else {
+      i++;
     }
   }
-  if (g_cache.size() >= 4) {
+}
+extern "C" size_t annhip_cache_size(void) { return g_cache.size(); }
+
+static bool same_key(const CacheEntry &e, const save_t *sv, const ftype *points) {
+  return e.save == sv && e.points == points;
+}
+
+// insert, replacing any entry with the same (save, points) key; oldest entry evicted when full
+static void cache_put(const save_t *sv, const ftype *points, u64 fp, annhip_index *ix) {
+  for (size_t i = 0; i < g_cache.size();) {
+    if (same_key(g_cache[i], sv, points)) {
+      annhip_index_destroy(g_cache[i].ix);
+      g_cache.erase(g_cache.begin() + i);
+    } else {
+      i++;
+    }
+  }
+  if (g_cache.size() >= ANN_CACHE_SLOTS) {
     annhip_index_destroy(g_cache.front().ix);
     g_cache.erase(g_cache.begin());
   }
-  annhip_index *ix = annhip_index_create(sv, points, 0, 0, sv->n);
   g_cache.push_back(CacheEntry{sv, points, sv->graph, sv->n, sv->k, sv->d_long, sv->tries, fp, ix});
+}
+
+static annhip_index *cache_get(const save_t *sv, const ftype *points) {
+  const u64 fp = fingerprint(sv, points);
+  for (size_t i = 0; i < g_cache.size();) {
+    CacheEntry &e = g_cache[i];
+    if (!same_key(e, sv, points)) {
+      i++;
+      continue;
+    }
+    if (e.fp == fp && e.graph == sv->graph && e.n == sv->n && e.k == sv->k && e.d == sv->d_long && e.T == sv->tries)
+      return e.ix;
+    annhip_index_destroy(e.ix);  // same addresses, different content: stale
+    g_cache.erase(g_cache.begin() + i);
+  }
+  annhip_index *ix = annhip_index_create(sv, points, 0, 0, sv->n);
+  cache_put(sv, points, fp, ix);
   return ix;
 }
 
@@ -1407,11 +1529,15 @@ extern "C" size_t *query_gpu(const save_t *save, const ftype *points, size_t ycn
                              ftype **dists_o) {
   RandGuard keep_callers_stream;
   gpu_init();
-  annhip_index *ix = cache_get(save, points);
+  const bool resident = env().cache_mode != 2;  // ANN_HIP_CACHE=off: upload per call, as the reference does
+  annhip_index *ix = resident ? cache_get(save, points) : annhip_index_create(save, points, 0, 0, save->n);
   const size_t k = save->k, d = save->d_long;
   size_t *result = (size_t *)malloc(sizeof(size_t) * (ycnt * k ? ycnt * k : 1));
   if (dists_o) *dists_o = (ftype *)malloc(sizeof(ftype) * (ycnt * k ? ycnt * k : 1));
-  if (!ycnt) return result;
+  if (!ycnt) {
+    if (!resident) annhip_index_destroy(ix);
+    return result;
+  }
   FT *y_dev = (FT *)ix->io_y.need(sizeof(FT) * ycnt * d);
   size_t *ids_dev = (size_t *)ix->io_ids.need(sizeof(size_t) * ycnt * k);
   FT *dist_dev = (FT *)ix->io_dist.need(sizeof(FT) * ycnt * k);
@@ -1420,6 +1546,7 @@ extern "C" size_t *query_gpu(const save_t *save, const ftype *points, size_t ycn
   HIPCHECK(hipStreamSynchronize(ix->stream));
   HIPCHECK(hipMemcpy(result, ids_dev, sizeof(size_t) * ycnt * k, hipMemcpyDeviceToHost));
   if (dists_o) HIPCHECK(hipMemcpy(*dists_o, dist_dev, sizeof(FT) * ycnt * k, hipMemcpyDeviceToHost));
+  if (!resident) annhip_index_destroy(ix);
   return result;
 }
 
@@ -1444,12 +1571,12 @@ extern "C" size_t *precomp_gpu(size_t n, size_t k, size_t d, const ftype *points
   ix->d_graph_dists = NULL;
   if (save) {
     annhip_index_export(ix, save);
-    // keep the freshly built index resident for the queries that normally follow (time_results.c:95-105)
-    if (g_cache.size() >= 4) {
-      annhip_index_destroy(g_cache.front().ix);
-      g_cache.erase(g_cache.begin());
-    }
-    g_cache.push_back(CacheEntry{save, points, save->graph, n, k, d, tries, fingerprint(save, points), ix});
+    // keep the freshly built index resident for the queries that normally follow (time_results.c:95-105); an older
+    // index built for the same save_t / points addresses (the reference's drivers reuse them in a loop) is replaced
+    if (env().cache_mode != 2)
+      cache_put(save, points, fingerprint(save, points), ix);
+    else
+      annhip_index_destroy(ix);
   } else {
     annhip_index_destroy(ix);
   }

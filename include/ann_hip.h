@@ -46,6 +46,18 @@ void annhip_index_export(const annhip_index *ix, save_t *save);
 int annhip_save_write(const save_t *save, const char *path);
 int annhip_save_read(const char *path, save_t *save);
 
+/* ---- residency cache behind query_gpu()/precomp_gpu() ------------------------------------------------------------ */
+/* The reference re-wraps points, graph and every table per call (alg.c:444-445,503-508); query_gpu() instead keeps up
+ * to four indexes resident, keyed by (save, points) addresses plus a content fingerprint: par_maxes, row_means and
+ * bases in full, 1 024 strided samples each of points, graph and every which_par[t].  In-place edits that miss the
+ * samples are NOT seen: call annhip_cache_drop(save) (the bundled free_save() does) or annhip_cache_clear() after
+ * editing, or set ANN_HIP_CACHE=strict (full content hash per call) / ANN_HIP_CACHE=off (upload per call).
+ * annhip_cache_size() = resident indexes.  annhip_reload_env() re-reads the ANN_HIP_* switches (they are read once). */
+void annhip_cache_clear(void);
+void annhip_cache_drop(const save_t *save);
+size_t annhip_cache_size(void);
+void annhip_reload_env(void);
+
 /* ---- precomp on the device (alg.c:342-434) ----------------------------------------------------- */
 /* Builds the index from ALL n rows on this device and keeps it resident.  Consumes libc random() in the
  * reference's order.  graph_dists_dev (device, ftype[n*k]) may be NULL. */
@@ -131,6 +143,14 @@ void annhip_widen_ids(annhip_index *ix, size_t count, const uint32_t *in_dev, si
  * graph precomp returns).  Synchronous. */
 void annhip_recall_ranks(size_t n, size_t d, size_t k, const ftype *points_dev, size_t ycnt, const ftype *y_dev,
                          const size_t *guess_dev, int self, unsigned long long *ranks_dev);
+
+/* ---- synthetic data of the reference's drivers ------------------------------------------------------ */
+/* out[0..count) = iid N(0,1) by Box-Muller on the CALLER's libc random() stream, value for value what genRand /
+ * rand_norm produce (/root/reference/time_results.c:10-13, randNorm.c:9-21), incl. the pending second value of a pair
+ * that the reference keeps between calls (annhip_synth_reset() forgets it, as a fresh process would).  Host memory;
+ * the draws are sequential, the libm part runs on several host threads. */
+void annhip_synth_randnorm(size_t count, ftype *out);
+void annhip_synth_reset(void);
 
 /* ---- measurement ---------------------------------------------------------------------------------- */
 /* profile != 0: bracket every stage1 launch with HIP events on the index's stream. */

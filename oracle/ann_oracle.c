@@ -10,7 +10,7 @@
  *
  * Parity status: PINNED.  tests/test_oracle_vs_ref.py checks every function
  * here bit-for-bit against the reference itself compiled from
- * /root/reference (oracle/build_ref.sh -> oracle/_ref/libref_{f32,f64}.so),
+ * /root/reference (`make -C oracle ref` -> oracle/_ref/libref_{f32,f64}.so),
  * and tests/test_oracle_golden.py checks it against the committed vectors in
  * tests/golden/ that tests/golden/make_golden.py generated from that build.
  *

@@ -29,15 +29,24 @@ def pytest_collection_modifyitems(config, items):
 
 @pytest.fixture(scope="session", autouse=True)
 def _built_artifacts():
-    """The built .so files normally travel with the snapshot; if one is missing on this box, build it (hipcc and gcc
-    are in the image) rather than let every test fail on an ImportError."""
+    """The built .so files normally travel with the snapshot; anything missing or out of date on this box is (re)built
+    (hipcc and gcc are in the image)."""
     import subprocess
     from approximatenn_amd import _lib
-    if not all(os.path.exists(_lib.lib_path(p)) for p in ("f32", "f64")):
-        _lib.build()
+    # always `make` (a no-op when everything is up to date): a header edited after the last build must never be
+    # tested through a stale binary
+    _lib.build()
     harness = os.path.join(ROOT, "tests", "harness")
-    if not os.path.exists(os.path.join(harness, "compare_results_f32")):
-        from oracle import oracle_py
-        oracle_py.build()
-        subprocess.call(["make", "-s", "-C", harness])
+    from oracle import oracle_py
+    oracle_py.build()
+    subprocess.call(["make", "-s", "-C", harness])
     yield
+
+
+@pytest.fixture(autouse=True)
+def _fresh_env_switches():
+    """The library caches its ANN_HIP_* switches; tests that set them call _lib.reload_env() themselves, and this
+    makes sure no test inherits another one's switches."""
+    yield
+    from approximatenn_amd import _lib
+    _lib.reload_env()

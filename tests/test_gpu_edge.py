@@ -3,6 +3,7 @@ import ctypes as C
 
 import numpy as np
 import pytest
+import torch
 
 import approximatenn_amd as A
 from oracle import oracle_py as O
@@ -162,6 +163,7 @@ def test_network_in_hbm_and_chunked_host_driven_exact_path(prec, monkeypatch):
     for exact in (False, True):
         if exact:
             monkeypatch.setenv("ANN_HIP_EXACT", "1")
+        A._lib.reload_env()
         O.srandom(9)
         ids, dd, save = A.precomp(pts, 6, 4)
         try:
@@ -171,3 +173,103 @@ def test_network_in_hbm_and_chunked_host_driven_exact_path(prec, monkeypatch):
         finally:
             A._lib.load(prec).annhip_cache_clear()
             save.free()
+
+
+@pytest.mark.parametrize("name", ["pow2_d64_f32", "k17_d100_f64", "defaults_d80_f32"])
+def test_index_file_roundtrip_into_the_hip_path(name, tmp_path):
+    """SURVEY 8(f)-1 end to end: build on the GPU, write the index file, read it back in a fresh Save, create a resident
+    index from the FILE and match the reference's recorded answers bit for bit."""
+    g = load_golden(name)
+    c, prec = g["cfg"], g["prec"]
+    pts = np.ascontiguousarray(g["points"])
+    O.srandom(c["seed"])
+    orc = O.CpuBackend(prec, "oracle")
+    orc.rand_norm_reset()
+    orc.gen_rand(c["n"] * c["d"] + (c["n"] * c["d"]) % 2)   # same libc stream position as the generator had
+    ids, dd, save = A.precomp(pts, c["k"], c["tries"], c["rb"], c["rlb"], c["ra"], c["rla"])
+    path = tmp_path / "index.ann"
+    try:
+        assert np.array_equal(ids, g["precomp_ids"])
+        save.write(path)
+    finally:
+        A._lib.load(prec).annhip_cache_clear()
+        save.free()
+    back = A.Save.read(prec, path)
+    try:
+        assert_save_equal(back.to_dict(), g["save"])
+        ix = A.Index.from_save(back, torch.from_numpy(pts).cuda())
+        r_ids, r_d, _ = ix.query(torch.from_numpy(np.ascontiguousarray(g["y"])).cuda())
+        torch.cuda.synchronize()
+        assert np.array_equal(r_ids.cpu().numpy().astype(np.uint64), g["query_ids"])
+        assert bits_equal(r_d.cpu().numpy(), g["query_dists"])
+        ix.close()
+        q_ids, q_d = A.query(back, pts, g["y"])   # and through the drop-in symbol, host pointers
+        assert np.array_equal(q_ids, g["query_ids"]) and bits_equal(q_d, g["query_dists"])
+    finally:
+        A._lib.load(prec).annhip_cache_clear()
+        back.free()
+
+
+def test_residency_cache_contract(monkeypatch):
+    """One resident index per (save, points) key; rebuilt indexes replace older ones; edits of sampled content and of
+    bases / row_means are detected; an edit of an UNSAMPLED table entry is detected in strict mode and after
+    annhip_cache_drop(), and -- the documented contract -- not otherwise."""
+    lib = A._lib.load("f32")
+    lib.annhip_cache_clear()
+    orc = O.CpuBackend("f32", "oracle")
+    O.srandom(4242)
+    orc.rand_norm_reset()
+    n, d, k, T, Q = 6000, 32, 5, 3, 64
+    pts = orc.gen_rand(n * d).reshape(n, d)
+    y = orc.gen_rand(Q * d).reshape(Q, d)
+    saves = []
+    try:
+        for rep in range(3):                      # the reference's drivers: same &save / points every iteration
+            O.srandom(11 + rep)
+            ids, dd, save = A.precomp(pts, k, T)
+            saves.append(save)
+            assert lib.annhip_cache_size() == rep + 1   # distinct save_t addresses here (Save objects are kept alive)
+        lib.annhip_cache_clear()
+        save = saves[-1]
+        arrays = save.to_dict()
+        want = orc.query(arrays, pts, y)
+        got = A.query(save, pts, y)
+        assert np.array_equal(got[0], want[0]) and bits_equal(got[1], want[1])
+        assert lib.annhip_cache_size() == 1
+        A.query(save, pts, y)
+        assert lib.annhip_cache_size() == 1      # hit, not a second upload
+        # --- an unsampled table entry: swap two ids inside one bucket row far from the strided samples
+        wp0 = np.ctypeslib.as_array(save.c.which_par[0], shape=((1 << int(save.c.d_short)) * int(save.c.par_maxes[0]),))
+        cnt = wp0.size
+        sampled = {(cnt - 1) * i // 1023 for i in range(1024)} if cnt > 1024 else set(range(cnt))
+        pm0 = int(save.c.par_maxes[0])
+        pos = next(p for p in range(0, cnt - 1, pm0) if wp0[p] < n and wp0[p + 1] < n and p not in sampled and p + 1 not in sampled)
+        wp0[pos], wp0[pos + 1] = wp0[pos + 1], wp0[pos]          # in place, same addresses
+        want2 = orc.query(save.to_dict(), pts, y)
+        stale = A.query(save, pts, y)
+        assert np.array_equal(stale[0], want[0])                 # documented: sampled fingerprint does not see it
+        lib.annhip_cache_drop(save.c)
+        assert lib.annhip_cache_size() == 0
+        fresh = A.query(save, pts, y)
+        assert np.array_equal(fresh[0], want2[0]) and bits_equal(fresh[1], want2[1])
+        wp0[pos], wp0[pos + 1] = wp0[pos + 1], wp0[pos]          # back
+        monkeypatch.setenv("ANN_HIP_CACHE", "strict")
+        A._lib.reload_env()
+        lib.annhip_cache_clear()
+        a1 = A.query(save, pts, y)
+        assert np.array_equal(a1[0], want[0])
+        wp0[pos], wp0[pos + 1] = wp0[pos + 1], wp0[pos]
+        a2 = A.query(save, pts, y)                               # strict: full content hash sees the swap
+        assert np.array_equal(a2[0], want2[0]) and bits_equal(a2[1], want2[1])
+        assert lib.annhip_cache_size() == 1
+        monkeypatch.setenv("ANN_HIP_CACHE", "off")
+        A._lib.reload_env()
+        lib.annhip_cache_clear()
+        a3 = A.query(save, pts, y)
+        assert np.array_equal(a3[0], want2[0]) and lib.annhip_cache_size() == 0
+    finally:
+        monkeypatch.delenv("ANN_HIP_CACHE", raising=False)
+        A._lib.reload_env()
+        lib.annhip_cache_clear()
+        for s_ in saves:
+            s_.free()

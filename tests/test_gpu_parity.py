@@ -31,9 +31,11 @@ def path_mode(request):
         os.environ["ANN_HIP_EXACT"] = "1"
     elif request.param == "select-unfused":
         os.environ["ANN_HIP_FUSE"] = "0"
+    A._lib.reload_env()
     yield request.param
     os.environ.pop("ANN_HIP_EXACT", None)
     os.environ.pop("ANN_HIP_FUSE", None)
+    A._lib.reload_env()
 
 
 @pytest.mark.parametrize("name", golden_cases())
@@ -75,7 +77,10 @@ def test_precomp_matches_golden(name, path_mode):
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])
 @pytest.mark.parametrize("case", [(3000, 64, 10, 10, 500), (2500, 128, 8, 6, 300), (1800, 80, 10, 10, 120),
-                                  (4000, 16, 5, 8, 700), (1200, 256, 10, 4, 64), (900, 40, 20, 3, 50)])
+                                  (4000, 16, 5, 8, 700), (1200, 256, 10, 4, 64), (900, 40, 20, 3, 50),
+                                  # k*tries just above a power of two: precomp skips the distance pass of the tries whose
+                                  # merged columns lie beyond the sorted prefix (Q1) -- 22 of 30, 13 of 14, all 9 scored
+                                  (2000, 32, 3, 30, 100), (1200, 32, 5, 14, 50), (1500, 64, 8, 9, 64)])
 def test_against_oracle_fresh_inputs(prec, case):
     """Seeded inputs never seen by the fixtures: GPU precomp+query vs the oracle, all fields bit-exact."""
     n, d, k, T, Q = case

@@ -51,3 +51,66 @@ def test_rejects_wrong_precision_truncation_and_corruption(tmp_path):
     (tmp_path / "junk.ann").write_bytes(b"not an index file at all" * 10)
     with pytest.raises(OSError):
         A.Save.read("f32", tmp_path / "junk.ann")
+
+
+def test_header_is_checked_against_the_file_size_before_anything_is_allocated(tmp_path):
+    """A header that promises more than the file holds (n, par_maxes, d_long blown up) must be refused up front --
+    no multi-terabyte malloc, no fread into NULL -- and so must a file with bytes appended."""
+    import struct
+    g = load_golden("tiny_appendixA_f32")
+    save = A.Save.from_dict("f32", g["save"])
+    path = tmp_path / "index.ann"
+    save.write(path)
+    blob = path.read_bytes()
+    assert blob[:8] == b"ANNSAVE2"
+    T = int(g["save"]["tries"])
+    for off, val in ((24, 1 << 40),            # n
+                     (48, 1 << 23),            # d_long
+                     (56, 1 << 50),            # par_maxes[0]
+                     (32, 1 << 30),            # k (then n <= k)
+                     (16, 4000)):              # tries
+        bad = bytearray(blob)
+        bad[off:off + 8] = struct.pack("<Q", val)
+        (tmp_path / "hdr.ann").write_bytes(bytes(bad))
+        with pytest.raises(OSError):
+            A.Save.read("f32", tmp_path / "hdr.ann")
+    (tmp_path / "long.ann").write_bytes(blob + b"\0" * 16)
+    with pytest.raises(OSError):
+        A.Save.read("f32", tmp_path / "long.ann")
+    assert T >= 1
+
+
+def test_ids_outside_their_range_are_refused_even_with_a_valid_checksum(tmp_path):
+    g = load_golden("tiny_appendixA_f32")
+    arrays = dict(g["save"])
+    arrays["which_par"] = [w.copy() for w in arrays["which_par"]]
+    arrays["which_par"][0][0, 0] = int(arrays["n"]) + 7          # neither a point id nor the padding n
+    save = A.Save.from_dict("f32", arrays)
+    path = tmp_path / "index.ann"
+    save.write(path)                                             # the writer does not judge; the checksum is valid
+    with pytest.raises(OSError):
+        A.Save.read("f32", path)
+
+
+def test_checksum_throughput(tmp_path):
+    """The word-wise checksum must not be the bottleneck of multi-GB index files (format 1's byte-wise FNV was)."""
+    import time
+    n, k, ds, T = 200_000, 10, 14, 2
+    rng = np.random.default_rng(0)
+    arrays = dict(tries=T, n=n, k=k, d_short=ds, d_long=16, par_maxes=np.array([40, 40], dtype=np.uint64),
+                  graph=rng.integers(0, n, size=(n, k), dtype=np.uint64),
+                  which_par=[rng.integers(0, n + 1, size=(1 << ds, 40), dtype=np.uint64) for _ in range(T)],
+                  row_means=np.zeros(16, dtype=np.float32), bases=np.zeros((T, ds, 16), dtype=np.float32))
+    save = A.Save.from_dict("f32", arrays)
+    path = tmp_path / "big.ann"
+    t0 = time.perf_counter()
+    save.write(path)
+    t1 = time.perf_counter()
+    back = A.Save.read("f32", path)
+    t2 = time.perf_counter()
+    try:
+        assert_save_equal(back.to_dict(), arrays)
+    finally:
+        back.free()
+    mb = os.path.getsize(path) / 1e6
+    assert mb / (t1 - t0) > 100 and mb / (t2 - t1) > 100, (mb, t1 - t0, t2 - t1)   # MB/s, generous lower bound
