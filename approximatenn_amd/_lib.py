@@ -83,15 +83,16 @@ def load(prec="f32"):
     lib.annhip_stream_collect.restype = C.c_int
     lib.annhip_stream_collect.argtypes = [vp, C.c_long, vp, vp]
     lib.annhip_stream_close.argtypes = [vp]
-    lib.annhip_codes.argtypes = [vp, sz, vp, u32p]
-    lib.annhip_stage1_local.argtypes = [vp, sz, vp, C.c_int, u32p, vp, u32p, u32p]
-    lib.annhip_merge_candidates.argtypes = [vp, C.c_int, sz, vp, u32p, vp, u32p]
-    lib.annhip_stage1_finalize.restype = C.c_long
-    lib.annhip_stage1_finalize.argtypes = [vp, sz, vp, u32p, u32p, u32p, vp, u32p]
+    lib.annhip_key_bytes.restype = sz
+    lib.annhip_key_bytes.argtypes = []
+    lib.annhip_sh_codes.argtypes = [vp, vp, sz, vp, sz, sz, u32p]
+    lib.annhip_sh_stage1.argtypes = [vp, vp, sz, vp, C.c_int, u32p, vp, u32p, u32p]
+    lib.annhip_sh_merge_finalize.argtypes = [vp, vp, C.c_int, sz, sz, sz, vp, u32p, u32p, vp]
+    lib.annhip_sh_stage2.argtypes = [vp, vp, sz, vp, C.c_int, u32p, vp, u32p]
+    lib.annhip_sh_final.argtypes = [vp, vp, C.c_int, sz, sz, sz, u32p, vp, vp, u32p, vp]
     lib.annhip_stage1_rows.argtypes = [vp, sz, vp, C.c_int, u32p, u32p, sz, u32p, vp]
-    lib.annhip_stage2_rows.argtypes = [vp, sz, vp, C.c_int, u32p, vp, u32p, vp]
+    lib.annhip_stage2_rows_list.argtypes = [vp, sz, vp, C.c_int, u32p, sz, u32p, vp, u32p, vp]
     lib.annhip_exact_select.argtypes = [vp, C.c_int, sz, u32p, vp, u32p, u32p, vp]
-    lib.annhip_widen_ids.argtypes = [vp, sz, u32p, vp]
     lib.annhip_recall_ranks.argtypes = [sz, sz, sz, vp, sz, vp, vp, C.c_int, vp]
     lib.annhip_profile.argtypes = [vp, C.c_int]
     lib.annhip_stats.argtypes = [vp, C.POINTER(C.c_double * 8), C.c_int]
@@ -118,9 +119,9 @@ def load(prec="f32"):
 EXPORTED = ["gpu_init", "gpu_cleanup", "register_cleanup", "query_gpu", "precomp_gpu", "annhip_precision",
             "annhip_index_create", "annhip_index_destroy", "annhip_index_info", "annhip_index_set_stream",
             "annhip_index_export", "annhip_index_reshard", "annhip_save_write", "annhip_save_read", "annhip_precomp_index", "annhip_query", "annhip_workspace_create", "annhip_workspace_destroy", "annhip_query_on", "annhip_stream_open", "annhip_stream_submit", "annhip_stream_collect", "annhip_stream_close",
-            "annhip_codes", "annhip_stage1_local",
-            "annhip_merge_candidates", "annhip_stage1_finalize", "annhip_stage1_rows", "annhip_stage2_rows", "annhip_exact_select",
-            "annhip_widen_ids", "annhip_recall_ranks", "annhip_profile", "annhip_stats", "annhip_stage_ms",
+            "annhip_key_bytes", "annhip_sh_codes", "annhip_sh_stage1", "annhip_sh_merge_finalize", "annhip_sh_stage2",
+            "annhip_sh_final", "annhip_stage1_rows", "annhip_stage2_rows_list", "annhip_exact_select",
+            "annhip_recall_ranks", "annhip_profile", "annhip_stats", "annhip_stage_ms",
             "annhip_cache_clear", "annhip_cache_drop", "annhip_cache_size", "annhip_reload_env",
             "annhip_synth_randnorm", "annhip_synth_reset"]
 DISPATCH_EXPORTED = ["precomp", "query", "free_save"]

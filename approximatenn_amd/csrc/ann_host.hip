@@ -552,7 +552,8 @@ __global__ void sum_u32_kernel(size_t count, const u32 *__restrict__ v, unsigned
 
 static void launch_stage1(annhip_index *ix, const QParams &P, size_t Q, const FT *y, int alias,
                           const u32 *codes, FT *cand_d, u32 *cand_i, u32 *nvt, u32 *nvo, hipStream_t s,
-                          const std::vector<TryInfo> &h_tries, bool use_seg, FusedTail F = FusedTail{0, 0, NULL, NULL, NULL, NULL, NULL}) {
+                          const std::vector<TryInfo> &h_tries, bool use_seg, FusedTail F = FusedTail{0, 0, NULL, NULL, NULL, NULL, NULL},
+                          Key *cand_key = NULL) {
   if (!Q) return;
   const int K1 = P.k + 1, W = stage1_waves(P.P1, (double)(P.hi - P.lo) / (double)P.n), cap = stage1_cap(W, K1);
   const size_t smem = stage1_lds_bytes(P, W, K1, cap, F.enabled ? F.len2 : 0);
@@ -579,11 +580,11 @@ static void launch_stage1(annhip_index *ix, const QParams &P, size_t Q, const FT
     if (use_seg) {                                                                                          \
       allow_lds(stage1_select_kernel<DD, true>, smem);                                                      \
       hipLaunchKernelGGL((stage1_select_kernel<DD, true>), dim3((unsigned)Q), dim3(64 * W), smem, s, P, (int)Q, y, \
-                         alias, codes, K1, cap, runs_used, cand_d, cand_i, nvt, nvo, F);                    \
+                         alias, codes, K1, cap, runs_used, cand_d, cand_i, nvt, nvo, F, cand_key);          \
     } else {                                                                                                \
       allow_lds(stage1_select_kernel<DD, false>, smem);                                                     \
       hipLaunchKernelGGL((stage1_select_kernel<DD, false>), dim3((unsigned)Q), dim3(64 * W), smem, s, P, (int)Q, y, \
-                         alias, codes, K1, cap, runs_used, cand_d, cand_i, nvt, nvo, F);                    \
+                         alias, codes, K1, cap, runs_used, cand_d, cand_i, nvt, nvo, F, cand_key);          \
     }                                                                                                       \
   } while (0)
   ANN_DISPATCH_D(P.d, CALL);
@@ -749,6 +750,14 @@ static void seg_mark(annhip_index *ix, std::vector<hipEvent_t> *marks, hipStream
   marks->push_back(e);
 }
 
+// Stage 1 reads code[i*Q + x] for the tries i that own a slot below Lc1, i.e. flat indices below
+// tries_used*Q of the [q*T+t] array, i.e. the codes of queries below ceil(tries_used*Q/T): only those are hashed.
+static size_t codes_needed(const annhip_index *ix, size_t Q) {
+  int tries_used = 0;
+  while (tries_used < ix->T && ix->h_tries[tries_used].off < ix->Lc1) tries_used++;
+  return std::min(Q, ((size_t)tries_used * Q + ix->T - 1) / ix->T);
+}
+
 // ----------------------------------------------------------------------------- query
 static long query_impl(annhip_index *ix, annhip_workspace &ws, hipStream_t s, size_t Q, const ftype *y_dev, int alias,
                        int mode, size_t *ids_dev, ftype *dists_dev) {
@@ -763,12 +772,7 @@ static long query_impl(annhip_index *ix, annhip_workspace &ws, hipStream_t s, si
   std::vector<hipEvent_t> marks_store, *marks = ix->profile ? &marks_store : NULL;
   seg_mark(ix, marks, s);
   u32 *codes = (u32 *)ws.codes.need(sizeof(u32) * Q * P.T);
-  {
-    int tries_used = 0;
-    while (tries_used < ix->T && ix->h_tries[tries_used].off < ix->Lc1) tries_used++;
-    const size_t qhash = std::min(Q, ((size_t)tries_used * Q + ix->T - 1) / ix->T);
-    launch_codes(P, qhash, y, codes, s);
-  }
+  launch_codes(P, codes_needed(ix, Q), y, codes, s);
   seg_mark(ix, marks, s);
   u32 *top_i = (u32 *)ws.top_i.need(sizeof(u32) * Q * k);
   FT *top_d = (FT *)ws.top_d.need(sizeof(FT) * Q * k);
@@ -950,70 +954,12 @@ extern "C" void annhip_stream_close(annhip_stream *st) {
 }
 
 // ----------------------------------------------------------------------------- staged API
-extern "C" void annhip_codes(annhip_index *ix, size_t Q, const ftype *y_dev, uint32_t *codes_dev) {
-  launch_codes(make_params(ix), Q, reinterpret_cast<const FT *>(y_dev), codes_dev, ix->stream);
-}
-
-extern "C" void annhip_stage1_local(annhip_index *ix, size_t Q, const ftype *y_dev, int alias,
-                                    const uint32_t *codes_dev, ftype *cand_dist_dev, uint32_t *cand_id_dev,
-                                    uint32_t *nvalid_dev) {
-  const QParams P = make_params(ix);
-  u32 *nvo = (u32 *)ix->ws.nvo.need(sizeof(u32) * Q);
-  launch_stage1(ix, P, Q, reinterpret_cast<const FT *>(y_dev), alias, codes_dev, reinterpret_cast<FT *>(cand_dist_dev),
-                cand_id_dev, nvalid_dev, nvo, ix->stream, ix->h_tries, ix->use_seg);
-  ix->queries += (double)Q;
-}
-
-extern "C" long annhip_stage1_finalize(annhip_index *ix, size_t Q, const ftype *cand_dist_dev,
-                                       const uint32_t *cand_id_dev, const uint32_t *nvalid_dev,
-                                       uint32_t *top_id_dev, ftype *top_dist_dev, uint32_t *flagged_dev) {
-  const QParams P = make_params(ix);
-  hipStream_t s = ix->stream;
-  u32 nflag = 0;
-  if ((u32)P.k > P.P1 || env().exact) {  // everything through the exact path
-    std::vector<u32> all(Q);
-    for (size_t i = 0; i < Q; i++) all[i] = (u32)i;
-    HIPCHECK(hipMemcpyAsync(flagged_dev, all.data(), sizeof(u32) * Q, hipMemcpyHostToDevice, s));
-    HIPCHECK(hipStreamSynchronize(s));
-    unsigned long long cur = 0;
-    HIPCHECK(hipMemcpy(&cur, ix->d_rows + 2, sizeof cur, hipMemcpyDeviceToHost));
-    cur += Q;
-    HIPCHECK(hipMemcpy(ix->d_rows + 2, &cur, sizeof cur, hipMemcpyHostToDevice));
-    return (long)Q;
-  }
-  zero_u32_kernel<<<1, 1, 0, s>>>(ix->ws.d_fcount);
-  hipLaunchKernelGGL(finalize1_kernel, dim3(grid_for(Q, 256, 1u << 30)), dim3(256), 0, s, (int)Q, P.k, P.k + 1, P.L1,
-                     P.P1, reinterpret_cast<const FT *>(cand_dist_dev), cand_id_dev, nvalid_dev, top_id_dev,
-                     reinterpret_cast<FT *>(top_dist_dev), P.k, 0, flagged_dev, ix->ws.d_fcount, ix->d_rows + 2);
-  HIPCHECK(hipGetLastError());
-  HIPCHECK(hipMemcpyAsync(&nflag, ix->ws.d_fcount, sizeof(u32), hipMemcpyDeviceToHost, s));
-  HIPCHECK(hipStreamSynchronize(s));
-  if (nflag > 1) {
-    // finalize1 appends with an atomic, so the order is arbitrary; every rank of a sharded host must see the
-    // SAME list (row i of the min-reduced distance rows has to be the same query everywhere): sort it.
-    std::vector<u32> fl(nflag);
-    HIPCHECK(hipMemcpy(fl.data(), flagged_dev, sizeof(u32) * nflag, hipMemcpyDeviceToHost));
-    std::sort(fl.begin(), fl.end());
-    HIPCHECK(hipMemcpy(flagged_dev, fl.data(), sizeof(u32) * nflag, hipMemcpyHostToDevice));
-  }
-  return (long)nflag;
-}
-
 extern "C" void annhip_stage1_rows(annhip_index *ix, size_t Q, const ftype *y_dev, int alias,
                                    const uint32_t *codes_dev, const uint32_t *qidx_dev, size_t nq,
                                    uint32_t *ids_dev, ftype *dist_dev) {
   const QParams P = make_params(ix);
   launch_rows<MODE_TABLE>(P, Q, reinterpret_cast<const FT *>(y_dev), alias, codes_dev, qidx_dev, 0, nq, P.Lc1, NULL,
                           NULL, ids_dev, reinterpret_cast<FT *>(dist_dev), ix->profile ? ix->d_rows + 8 : NULL, ix->stream);
-}
-
-extern "C" void annhip_stage2_rows(annhip_index *ix, size_t Q, const ftype *y_dev, int alias,
-                                   const uint32_t *top_id_dev, const ftype *top_dist_dev, uint32_t *ids_dev,
-                                   ftype *dist_dev) {
-  const QParams P = make_params(ix);
-  launch_rows<MODE_GRAPH>(P, Q, reinterpret_cast<const FT *>(y_dev), alias, NULL, NULL, 0, Q, P.Lc2, top_id_dev,
-                          reinterpret_cast<const FT *>(top_dist_dev), ids_dev, reinterpret_cast<FT *>(dist_dev),
-                          ix->profile ? ix->d_rows + 8 : NULL, ix->stream);
 }
 
 extern "C" void annhip_exact_select(annhip_index *ix, int stage, size_t nq, uint32_t *ids_dev, ftype *dist_dev,
@@ -1023,20 +969,77 @@ extern "C" void annhip_exact_select(annhip_index *ix, int stage, size_t nq, uint
                       out_id_dev, reinterpret_cast<FT *>(out_dist_dev), (int)ix->k, 0, ix->stream);
 }
 
-extern "C" void annhip_merge_candidates(annhip_index *ix, int ndev, size_t Q, const ftype *in_dist_dev,
-                                        const uint32_t *in_id_dev, ftype *out_dist_dev, uint32_t *out_id_dev) {
-  if (ndev < 1 || ndev > 16) die("annhip_merge_candidates supports 1..16 devices");
-  if (!Q) return;
-  hipLaunchKernelGGL(merge_candidates_kernel, dim3(grid_for(Q, 128, 1u << 30)), dim3(128), 0, ix->stream, ndev, (int)Q,
-                     (int)ix->k + 1, reinterpret_cast<const FT *>(in_dist_dev), in_id_dev,
-                     reinterpret_cast<FT *>(out_dist_dev), out_id_dev);
+// ---- point-sharded hosts, owner protocol (approximatenn_amd/sharded.py).  Every call is
+// asynchronous on the given HIP stream and touches no index-owned scratch, so several batches can be in flight.
+extern "C" size_t annhip_key_bytes(void) { return sizeof(Key); }
+
+extern "C" void annhip_sh_codes(annhip_index *ix, void *hip_stream, size_t Q, const ftype *y_dev, size_t q_lo, size_t q_hi,
+                                uint32_t *codes_slice_dev) {
+  const size_t hi = std::min(std::min(q_hi, Q), codes_needed(ix, Q));
+  if (hi <= q_lo) return;
+  launch_codes(make_params(ix), hi - q_lo, reinterpret_cast<const FT *>(y_dev) + q_lo * ix->d, codes_slice_dev,
+               (hipStream_t)hip_stream);
+}
+
+extern "C" void annhip_sh_stage1(annhip_index *ix, void *hip_stream, size_t Q, const ftype *y_dev, int alias,
+                                 const uint32_t *codes_dev, void *keys_dev, uint32_t *nvalid_dev, uint32_t *nown_dev) {
+  const QParams P = make_params(ix);
+  if ((u32)P.k > P.P1) die("annhip_sh_stage1: k exceeds the sorted prefix; use the exact path (annhip_stage1_rows)");
+  launch_stage1(ix, P, Q, reinterpret_cast<const FT *>(y_dev), alias, codes_dev, NULL, NULL, nvalid_dev, nown_dev,
+                (hipStream_t)hip_stream, ix->h_tries, ix->use_seg, FusedTail{0, 0, NULL, NULL, NULL, NULL, NULL},
+                reinterpret_cast<Key *>(keys_dev));
+  ix->queries += (double)Q;
+}
+
+extern "C" void annhip_sh_merge_finalize(annhip_index *ix, void *hip_stream, int ndev, size_t Q, size_t q_lo, size_t qs,
+                                         const void *keys_in_dev, const uint32_t *nvalid_dev, uint32_t *top_id_dev,
+                                         ftype *top_dist_dev) {
+  if (ndev < 1 || ndev > 16) die("annhip_sh_merge_finalize supports 1..16 devices");
+  if (!qs) return;
+  const size_t nq = q_lo < Q ? std::min(qs, Q - q_lo) : 0;
+  hipLaunchKernelGGL(merge_finalize_kernel, dim3(grid_for(qs, 128, 1u << 30)), dim3(128), 0, (hipStream_t)hip_stream, ndev,
+                     (int)nq, (u32)q_lo, (u32)qs, (int)ix->k + 1, (int)ix->k, ix->L1, ix->P1,
+                     reinterpret_cast<const Key *>(keys_in_dev), nvalid_dev, top_id_dev, reinterpret_cast<FT *>(top_dist_dev),
+                     ix->d_rows + 2);
   HIPCHECK(hipGetLastError());
 }
 
-extern "C" void annhip_widen_ids(annhip_index *ix, size_t count, const uint32_t *in_dev, size_t *out_dev) {
-  if (!count) return;
-  widen_ids_kernel<<<grid_for(count, 256, 1u << 30), 256, 0, ix->stream>>>(count, in_dev, out_dev);
+extern "C" void annhip_sh_stage2(annhip_index *ix, void *hip_stream, size_t Q, const ftype *y_dev, int alias,
+                                 const uint32_t *top_id_all_dev, ftype *dist_out_dev, uint32_t *flagged_dev) {
+  const QParams P = make_params(ix);
+  hipStream_t s = (hipStream_t)hip_stream;
+  zero_u32_kernel<<<1, 1, 0, s>>>(flagged_dev);  // flagged_dev = {count, query indices...}, Q + 1 entries
+  launch_rows<MODE_GRAPH_DIST>(P, Q, reinterpret_cast<const FT *>(y_dev), alias, NULL, NULL, 0, Q, P.Lc2, top_id_all_dev,
+                               NULL, flagged_dev, reinterpret_cast<FT *>(dist_out_dev), ix->profile ? ix->d_rows + 8 : NULL, s);
+}
+
+extern "C" void annhip_sh_final(annhip_index *ix, void *hip_stream, int ndev, size_t Q, size_t q_lo, size_t qs,
+                                const uint32_t *top_id_dev, const ftype *top_dist_dev, const ftype *dist_in_dev,
+                                uint32_t *out_id_dev, ftype *out_dist_dev) {
+  if (!qs) return;
+  const size_t nq = q_lo < Q ? std::min(qs, Q - q_lo) : 0;
+  const size_t smem = (size_t)ix->Lc2 * (sizeof(FT) + sizeof(u32));
+  if (smem > 150 * 1024) die("annhip_sh_final: stage-2 row does not fit LDS");
+  const int lk = ann_lg(ix->L2);
+  unsigned npairs = 8u << (lk > 4 ? lk - 4 : 0);
+  unsigned block = npairs >= 1024 ? 1024 : ((npairs + 63) / 64) * 64;
+  if (block < 64) block = 64;
+  allow_lds(final_select_kernel, smem);
+  hipLaunchKernelGGL(final_select_kernel, dim3((unsigned)std::min<size_t>(qs, 1u << 20)), dim3(block), smem,
+                     (hipStream_t)hip_stream, ndev, (int)nq, (u32)q_lo, (u32)qs, (u32)ix->n, (int)ix->k, ix->L2, ix->Lc2,
+                     ix->d_graph, top_id_dev, reinterpret_cast<const FT *>(top_dist_dev),
+                     reinterpret_cast<const FT *>(dist_in_dev), out_id_dev, reinterpret_cast<FT *>(out_dist_dev));
   HIPCHECK(hipGetLastError());
+}
+
+// stage-2 rows (ids + distances, Lc2 each) of the listed queries only: the repair pass of flagged queries
+extern "C" void annhip_stage2_rows_list(annhip_index *ix, size_t Q, const ftype *y_dev, int alias, const uint32_t *qidx_dev,
+                                        size_t nq, const uint32_t *top_id_dev, const ftype *top_dist_dev,
+                                        uint32_t *ids_dev, ftype *dist_dev) {
+  const QParams P = make_params(ix);
+  launch_rows<MODE_GRAPH>(P, Q, reinterpret_cast<const FT *>(y_dev), alias, NULL, qidx_dev, 0, nq, P.Lc2, top_id_dev,
+                          reinterpret_cast<const FT *>(top_dist_dev), ids_dev, reinterpret_cast<FT *>(dist_dev),
+                          ix->profile ? ix->d_rows + 8 : NULL, ix->stream);
 }
 
 extern "C" void annhip_profile(annhip_index *ix, int profile) { ix->profile = profile != 0; }

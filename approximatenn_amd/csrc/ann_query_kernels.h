@@ -15,7 +15,8 @@
 //   row_dists           exact path / stage 2: every needed slot's id and distance, in slot order
 //                       (shufcomp alg.c:438-452, supercharge compute.cl:252-263, compdists alg.c:233-242)
 //   exact_select        the reference's network + rdups + network, literally    (alg.c:224-230)
-//   merge_candidates    multi-GPU: G sorted candidate lists -> the k+1 globally best
+//   merge_finalize /    multi-GPU (owner protocol): G sorted candidate lists -> the k globally best + the selection
+//   final_select        proof; min over the devices' partial stage-2 rows + the reference's network
 //
 // Only slots below ann_need_len() are ever produced.
 #pragma once
@@ -357,7 +358,8 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
                                                             FT *__restrict__ cand_dist,
                                                             u32 *__restrict__ cand_id,
                                                             u32 *__restrict__ nv_tot,
-                                                            u32 *__restrict__ nv_own, FusedTail F) {
+                                                            u32 *__restrict__ nv_own, FusedTail F,
+                                                            Key *__restrict__ cand_key) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = lane_id(), w = threadIdx.x >> 6, W = blockDim.x >> 6;
   const u32 x = blockIdx.x;
@@ -512,9 +514,13 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
     wave_lds_sync();
     const int m = wave_select_smallest(S.kbuf, total, K1, S.kout);
     if (!F.enabled) {
-      for (int i = lane; i < K1; i += ANN_WAVE) {
-        cand_dist[(size_t)x * K1 + i] = i < m ? key_dist(S.kout[i]) : ft_inf();
-        cand_id[(size_t)x * K1 + i] = i < m ? key_id(S.kout[i]) : ANN_ID_NONE;
+      if (cand_key) {  // sharded hosts: one packed (dist,id) key per candidate, the unit their exchange moves
+        for (int i = lane; i < K1; i += ANN_WAVE) cand_key[(size_t)x * K1 + i] = i < m ? S.kout[i] : key_make(ft_inf(), ANN_ID_NONE);
+      } else {
+        for (int i = lane; i < K1; i += ANN_WAVE) {
+          cand_dist[(size_t)x * K1 + i] = i < m ? key_dist(S.kout[i]) : ft_inf();
+          cand_id[(size_t)x * K1 + i] = i < m ? key_id(S.kout[i]) : ANN_ID_NONE;
+        }
       }
       if (lane == 0) {
         nv_tot[x] = cnts[0];
@@ -780,7 +786,11 @@ __global__ void finalize1_kernel(int Q, int k, int K1, u32 L1, u32 P1, const FT 
 //               graph neighbour of top[y] (sentinel parents give graph[0][z] | n, Q7)   (len = Lc2)
 // Slots this device does not own, sentinels and the excluded self row get +inf; a multi-GPU caller
 // min-reduces the distance rows across devices before exact_select.
-enum { MODE_TABLE = 0, MODE_GRAPH = 1 };
+//   MODE_GRAPH_DIST: stage-2 row of a point-sharded host: distances of slots [k, len) only, no ids (the query's owner
+//               derives them itself), row stride len - k; queries whose top-k is flagged (ANN_ID_FLAG) are skipped
+//               and appended to flist
+enum { MODE_TABLE = 0, MODE_GRAPH = 1, MODE_GRAPH_DIST = 2 };
+#define ANN_ID_FLAG 0xFFFFFFFEu  // top_id[x][0] of a query whose stage 1 has to be redone by the exact path
 #define ANN_RD_CHUNK 2048
 
 template <int D, int MODE>
@@ -801,8 +811,16 @@ __global__ __launch_bounds__(256) void row_dists_kernel(QParams P, int Q, const 
   const int lane = lane_id(), w = threadIdx.x >> 6, W = blockDim.x >> 6;
   for (u32 row = blockIdx.x; row < nrows; row += gridDim.x) {
   const u32 x = qidx ? qidx[row] : xbase + row;
-  u32 *ids_row = ids_out + (size_t)row * len;
-  FT *dist_row = dist_out + (size_t)row * len;
+  if constexpr (MODE == MODE_GRAPH_DIST) {
+    if (top_id[(size_t)x * P.k] == ANN_ID_FLAG) {  // workgroup-uniform
+      if (threadIdx.x == 0 && blockIdx.y == 0) ids_out[1 + atomicAdd(&ids_out[0], 1u)] = x;  // ids_out = {count, list...}
+      continue;
+    }
+  }
+  constexpr bool DIST_ONLY = MODE == MODE_GRAPH_DIST;
+  const u32 skip = DIST_ONLY ? (u32)P.k : 0u;  // columns [0, skip) are not stored
+  u32 *ids_row = DIST_ONLY ? NULL : ids_out + (size_t)row * len;
+  FT *dist_row = dist_out + (size_t)row * (len - skip) - skip;
   unsigned char *sp = smem;
   u32 *lslot = reinterpret_cast<u32 *>(sp);           sp += sizeof(u32) * chunk;  // chunk <= ANN_RD_CHUNK
   u32 *lid = reinterpret_cast<u32 *>(sp);             sp += sizeof(u32) * chunk;
@@ -846,6 +864,7 @@ __global__ __launch_bounds__(256) void row_dists_kernel(QParams P, int Q, const 
       } else {
         const u32 k = P.k;
         if (j < k) {
+          if (DIST_ONLY) continue;
           id = top_id[(size_t)x * k + j];
           given = true;
         } else {
@@ -854,7 +873,7 @@ __global__ __launch_bounds__(256) void row_dists_kernel(QParams P, int Q, const 
           id = parent < P.n ? P.graph[(size_t)parent * k + z] : (P.graph[z] | P.n);
         }
       }
-      ids_row[j] = id;
+      if (!DIST_ONLY) ids_row[j] = id;
       if (given) {
         dist_row[j] = top_dist[(size_t)x * P.k + j];
       } else {
@@ -959,36 +978,99 @@ __global__ __launch_bounds__(1024) void exact_select_kernel(u32 L, u32 len, u32 
   }
 }
 
-// ------------------------------------------------------------------------------- merge_candidates
-// Multi-GPU exchange 1: G devices each contributed K1 ascending distinct (dist,id) keys per query (ids are
-// disjoint across devices).  One thread per query merges the G sorted lists into the K1 globally smallest.
-// in: [G][Q][K1] (the layout an all-gather into one tensor produces); out: [Q][K1], same format as stage1_select.
-__global__ void merge_candidates_kernel(int G, int Q, int K1, const FT *__restrict__ in_d,
-                                        const u32 *__restrict__ in_i, FT *__restrict__ out_d,
-                                        u32 *__restrict__ out_i) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  if (x >= Q) return;
+// ---------------------------------------------------------------- point-sharded hosts, owner protocol
+// Queries are dealt to OWNER devices in contiguous slices of qs.  After the all-to-all of stage-1 candidates the
+// owner holds, for each of its nq queries, G ascending lists of K1 distinct packed keys (ids disjoint across
+// devices): in[g][xl][K1], xl = query - qbase.  One thread per query merges them to the K1 globally smallest and
+// applies finalize1's proof (see finalize1_kernel).  Accepted: top_id/top_dist[xl][0..k).  Rejected:
+// top_id[xl][0] = ANN_ID_FLAG -- every device sees the flag after the all-gather of top_id and joins the exact path.
+__global__ void merge_finalize_kernel(int G, int nq, u32 qbase, u32 qs, int K1, int k, u32 L1, u32 P1,
+                                      const Key *__restrict__ in, const u32 *__restrict__ nv_tot,
+                                      u32 *__restrict__ top_id, FT *__restrict__ top_dist,
+                                      unsigned long long *__restrict__ exact_total) {
+  const int xl = blockIdx.x * blockDim.x + threadIdx.x;
+  if (xl >= (int)qs) return;
+  u32 *ti = top_id + (size_t)xl * k;
+  FT *td = top_dist + (size_t)xl * k;
+  if (xl >= nq) {  // padding slot of the last slice: defined content for the collectives, never read as a query
+    for (int t = 0; t < k; t++) ti[t] = ANN_ID_NONE, td[t] = ft_inf();
+    return;
+  }
   int head[16];  // G <= 16
   for (int g = 0; g < G; g++) head[g] = 0;
+  bool flag = (u32)k > P1 || K1 != k + 1;
+  int m = 0;
+  UB prev_bits = 0;
   for (int t = 0; t < K1; t++) {
     int best = -1;
     Key bk = key_max();
     for (int g = 0; g < G; g++) {
       if (head[g] >= K1) continue;
-      const size_t at = ((size_t)g * Q + x) * K1 + head[g];
-      const u32 id = in_i[at];
-      if (id == ANN_ID_NONE) continue;  // padding: this list is exhausted
-      const Key k = key_make(in_d[at], id);
-      if (best < 0 || key_less(k, bk)) best = g, bk = k;
+      const Key c = in[((size_t)g * qs + xl) * K1 + head[g]];
+      if (key_id(c) == ANN_ID_NONE) continue;  // padding: this list is exhausted
+      if (best < 0 || key_less(c, bk)) best = g, bk = c;
     }
-    if (best < 0) {
-      out_d[(size_t)x * K1 + t] = ft_inf();
-      out_i[(size_t)x * K1 + t] = ANN_ID_NONE;
-    } else {
-      out_d[(size_t)x * K1 + t] = key_dist(bk);
-      out_i[(size_t)x * K1 + t] = key_id(bk);
-      head[best]++;
+    if (best < 0) break;
+    head[best]++;
+    const UB bits = ft_bits(key_dist(bk));
+    if (m > 0 && bits == prev_bits) flag = true;  // two different ids at one distance: the network decides (Q17)
+    prev_bits = bits;
+    if (t < k) ti[t] = key_id(bk), td[t] = key_dist(bk);
+    if (t == k - 1 && !(key_dist(bk) < ft_inf())) flag = true;
+    m++;
+  }
+  if (m < k) flag = true;
+  if (L1 > P1 && nv_tot[qbase + xl] >= P1) flag = true;
+  if (flag) {
+    ti[0] = ANN_ID_FLAG;
+    if (exact_total) atomicAdd(exact_total, 1ull);
+  }
+}
+
+// The owner's final step: stage-2 row of query qbase+xl = its top-k (ids, distances) followed by the neighbours of
+// the top-k (supercharge, compute.cl:252-263; ids derived here, distances = min over the G devices' partial rows
+// in2[g][xl][len-k], +inf where a device does not own the slot), then the reference's network + rdups + network
+// (alg.c:224-230) in LDS; first k entries out.  Flagged queries are left to the repair pass.
+__global__ __launch_bounds__(1024) void final_select_kernel(int G, int nq, u32 qbase, u32 qs, u32 n, int k, u32 L, u32 len,
+                                                           const u32 *__restrict__ graph,
+                                                           const u32 *__restrict__ top_id,
+                                                           const FT *__restrict__ top_dist,
+                                                           const FT *__restrict__ in2, u32 *__restrict__ out_id,
+                                                           FT *__restrict__ out_dist) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  FT *sd = reinterpret_cast<FT *>(smem);
+  u32 *si = reinterpret_cast<u32 *>(sd + len);
+  const u32 w2 = len - (u32)k;
+  for (u32 xl = blockIdx.x; xl < qs; xl += gridDim.x) {
+    const u32 *ti = top_id + (size_t)xl * k;
+    if (xl >= (u32)nq || ti[0] == ANN_ID_FLAG) {  // workgroup-uniform
+      for (int t = threadIdx.x; t < k; t += blockDim.x) {
+        out_id[(size_t)xl * k + t] = xl >= (u32)nq ? ANN_ID_NONE : ANN_ID_FLAG;
+        out_dist[(size_t)xl * k + t] = ft_inf();
+      }
+      continue;
     }
+    for (u32 j = threadIdx.x; j < len; j += blockDim.x) {
+      if (j < (u32)k) {
+        si[j] = ti[j], sd[j] = top_dist[(size_t)xl * k + j];
+      } else {
+        const u32 parent = ti[j / k - 1], z = j % k;
+        si[j] = parent < n ? graph[(size_t)parent * k + z] : (graph[z] | n);  // Q7
+        FT best = ft_inf();
+        for (int g = 0; g < G; g++) {
+          const FT v = in2[((size_t)g * qs + xl) * w2 + (j - k)];
+          best = v < best ? v : best;
+        }
+        sd[j] = best;
+      }
+    }
+    __syncthreads();
+    block_topk_stage<true>(L, len, sd, si);
+    for (int t = threadIdx.x; t < k; t += blockDim.x) {
+      out_id[(size_t)xl * k + t] = si[t];
+      out_dist[(size_t)xl * k + t] = sd[t];
+    }
+    __syncthreads();
   }
 }
 

@@ -1,27 +1,44 @@
 """Point-sharded query() across the GPUs of one node (one process per GPU, torch.distributed over RCCL/xGMI).
 
-The reference is single-device; this is the multi-GPU design BASELINE.json's north_star asks for:
+The reference is single-device; this is the multi-GPU design BASELINE.json's north_star asks for.
 
 * rank g owns point rows [g*n/G, (g+1)*n/G) in HBM; bucket tables, graph, projection rows are replicated (ids only);
-* every rank sees the whole query batch (results depend on the batch composition) and derives the
-  identical candidate row per query, but gathers rows and computes distances only for ids it owns;
-* exchange 0: each rank hashes one slice of the batch, the codes (4*T bytes per query) are all-gathered;
-* exchange 1: all-gather of each rank's k+1 best distinct (dist,id) candidates per query  (G*(k+1)*8 B/query),
-  merged by a device kernel (annhip_merge_candidates) to the global k+1 best; the same proof as on one GPU
-  (annhip_stage1_finalize) decides which queries need the exact path; for those (rare) the full distance rows
-  are min-all-reduced;
-* exchange 2: min-reduce-scatter of the stage-2 distance rows (Lc2 values per query, 65 at k=10): each rank runs
-  the reference's network on its slice of the queries only, and the final ids/distances are all-gathered.
-  (Plain all-gather / min-all-reduce forms are kept as the fallback: fast=False, gloo, uneven batches.)
+* every rank sees the whole query batch (results depend on the batch composition) and derives the identical
+  candidate row per query, but gathers rows and computes distances only for the ids it owns;
+* every query has an OWNER rank (contiguous slices of qs = ceil(Q/G) queries) that does its merges and its networks.
+
+One step (5 collectives; the data path never touches the host):
+
+  0. each rank hashes its own slice of the batch                     -> all-gather of the codes (4*T B/query)
+  1. stage 1 on ALL queries over the rows this rank owns: k+1 best distinct packed (dist,id) keys per query
+                                                                     -> all-to-all: keys go to the query's owner
+     ((k+1)*8 B per query and rank; xGMI is point-to-point, so the 7 peers' slices travel on 7 different links)
+  2. owner: merge the G lists + the single-GPU selection proof (annhip_sh_merge_finalize); rejected queries are
+     flagged in place                                                -> all-gather of the top-k ids (4*k B/query)
+  3. every rank: distances of the neighbour-of-neighbour slots it owns (annhip_sh_stage2)
+                                                                     -> all-to-all: partial rows go to the owner
+  4. owner: min over the G partial rows, the reference's network on the stage-2 row (annhip_sh_final)
+                                                                     -> all-gather of ids+distances (one packed buffer)
+
+Flagged queries (exact ties between different ids, fewer than k candidates: ~0.5 per 10k at cfg3) are REPAIRED after
+the step: all ranks compute their part of the full distance rows, two MIN all-reduces, the literal network, and the
+result rows are patched.  The flagged count is the only thing the host reads back, and it does so in collect(), not
+in the middle of the step: with submit()/collect() two batches are in flight on two HIP streams, so batch i+1's
+gather runs underneath batch i's exchanges and the host's read-back.
+
+If the backend cannot do all_to_all_single the same steps run with an all-gather + local slice instead
+(exchange="allgather": G times the traffic, identical results); the choice is agreed on by all ranks at start-up.
 
 Every rank ends with the same ids/distances, bit-identical to the single-GPU / reference result.
 
-`engine` is anything with the HipEngine methods below (tests drive the same orchestration with a CPU engine
-built on the oracle under gloo); `dist` is torch.distributed or None for a single process.
+`engine` is anything with the HipEngine methods below (tests drive the same orchestration with a CPU engine built on
+the oracle under gloo); `dist` is torch.distributed (or a stand-in) or None for a single process.
 """
-import ctypes as C
+import os
 
 import torch
+
+ID_FLAG = 0xFFFFFFFE  # ann_query_kernels.h: ANN_ID_FLAG
 
 
 def _u32(t):
@@ -34,51 +51,57 @@ class HipEngine:
 
     def __init__(self, ix):
         self.ix, self.lib, self.h = ix, ix.lib, ix.h
-        self.k, self.T, self.Lc1, self.Lc2 = ix.k, ix.tries, ix.Lc1, ix.Lc2
+        self.k, self.T, self.Lc1, self.Lc2, self.P1 = ix.k, ix.tries, ix.Lc1, ix.Lc2, ix.P1
         self.ft = torch.float32 if ix.prec == "f32" else torch.float64
+        self.key_words = self.lib.annhip_key_bytes() // 8
+        self.device = None
+        self._stream = None  # raw hipStream_t of the lane being enqueued (None = the default stream)
 
-    def _e(self, shape, dtype, like):
+    # -- lanes: one HIP stream per in-flight batch
+    def new_stream(self, device):
+        return torch.cuda.Stream(device=device)
+
+    def use(self, stream):
+        self._stream = stream.cuda_stream if stream is not None else None
+        self.lib.annhip_index_set_stream(self.h, self._stream)
+        return torch.cuda.stream(stream)
+
+    def empty(self, shape, dtype, like):
         return torch.empty(shape, dtype=dtype, device=like.device)
 
-    def codes(self, y):
-        out = self._e((y.shape[0] * self.T,), torch.int32, y)
-        self.lib.annhip_codes(self.h, y.shape[0], y.data_ptr(), out.data_ptr())
-        return out
+    # -- owner protocol
+    def sh_codes(self, y, q_lo, q_hi, out):
+        self.lib.annhip_sh_codes(self.h, self._stream, y.shape[0], y.data_ptr(), q_lo, q_hi, out.data_ptr())
 
-    def stage1_local(self, y, alias, codes):
-        Q, K1 = y.shape[0], self.k + 1
-        cd, ci, nv = self._e((Q, K1), self.ft, y), self._e((Q, K1), torch.int32, y), self._e((Q,), torch.int32, y)
-        self.lib.annhip_stage1_local(self.h, Q, y.data_ptr(), int(alias), codes.data_ptr(), cd.data_ptr(), ci.data_ptr(),
-                                     nv.data_ptr())
-        return cd, ci, nv
+    def sh_stage1(self, y, alias, codes, keys, nvalid, nown):
+        self.lib.annhip_sh_stage1(self.h, self._stream, y.shape[0], y.data_ptr(), int(alias), codes.data_ptr(),
+                                  keys.data_ptr(), nvalid.data_ptr(), nown.data_ptr())
 
-    def merge(self, ndev, all_d, all_i):
-        """all_d/all_i: [ndev, Q, k+1] gathered candidates -> the k+1 globally best per query."""
-        Q, K1 = all_d.shape[1], all_d.shape[2]
-        md, mi = self._e((Q, K1), self.ft, all_d), self._e((Q, K1), torch.int32, all_d)
-        self.lib.annhip_merge_candidates(self.h, ndev, Q, all_d.data_ptr(), all_i.data_ptr(), md.data_ptr(), mi.data_ptr())
-        return md, mi
+    def sh_merge_finalize(self, G, Q, q_lo, qs, keys_in, nvalid, top_i, top_d):
+        self.lib.annhip_sh_merge_finalize(self.h, self._stream, G, Q, q_lo, qs, keys_in.data_ptr(), nvalid.data_ptr(),
+                                          top_i.data_ptr(), top_d.data_ptr())
 
-    def finalize(self, cd, ci, nv):
-        Q = cd.shape[0]
-        top_i, top_d = self._e((Q, self.k), torch.int32, cd), self._e((Q, self.k), self.ft, cd)
-        fl = self._e((Q,), torch.int32, cd)
-        nf = self.lib.annhip_stage1_finalize(self.h, Q, cd.data_ptr(), ci.data_ptr(), nv.data_ptr(), top_i.data_ptr(),
-                                             top_d.data_ptr(), fl.data_ptr())
-        return top_i, top_d, fl[:nf]
+    def sh_stage2(self, y, alias, top_all, dist_out, flagged):
+        self.lib.annhip_sh_stage2(self.h, self._stream, y.shape[0], y.data_ptr(), int(alias), top_all.data_ptr(),
+                                  dist_out.data_ptr(), flagged.data_ptr())
 
+    def sh_final(self, G, Q, q_lo, qs, top_i, top_d, dist_in, out_i, out_d):
+        self.lib.annhip_sh_final(self.h, self._stream, G, Q, q_lo, qs, top_i.data_ptr(), top_d.data_ptr(), dist_in.data_ptr(),
+                                 out_i.data_ptr(), out_d.data_ptr())
+
+    # -- exact path (repair of flagged queries); these run on the index's stream (set by use())
     def stage1_rows(self, y, alias, codes, qidx):
         nq = qidx.shape[0]
-        ids, dd = self._e((nq, self.Lc1), torch.int32, y), self._e((nq, self.Lc1), self.ft, y)
+        ids, dd = self.empty((nq, self.Lc1), torch.int32, y), self.empty((nq, self.Lc1), self.ft, y)
         self.lib.annhip_stage1_rows(self.h, y.shape[0], y.data_ptr(), int(alias), codes.data_ptr(), qidx.data_ptr(), nq,
                                     ids.data_ptr(), dd.data_ptr())
         return ids, dd
 
-    def stage2_rows(self, y, alias, top_i, top_d):
-        Q = y.shape[0]
-        ids, dd = self._e((Q, self.Lc2), torch.int32, y), self._e((Q, self.Lc2), self.ft, y)
-        self.lib.annhip_stage2_rows(self.h, Q, y.data_ptr(), int(alias), top_i.data_ptr(), top_d.data_ptr(), ids.data_ptr(),
-                                    dd.data_ptr())
+    def stage2_rows_list(self, y, alias, qidx, top_i, top_d):
+        nq = qidx.shape[0]
+        ids, dd = self.empty((nq, self.Lc2), torch.int32, y), self.empty((nq, self.Lc2), self.ft, y)
+        self.lib.annhip_stage2_rows_list(self.h, y.shape[0], y.data_ptr(), int(alias), qidx.data_ptr(), nq, top_i.data_ptr(),
+                                         top_d.data_ptr(), ids.data_ptr(), dd.data_ptr())
         return ids, dd
 
     def exact_select(self, stage, ids, dd, qidx, out_i, out_d):
@@ -87,43 +110,116 @@ class HipEngine:
                                      qidx.data_ptr() if qidx is not None else None, out_i.data_ptr(), out_d.data_ptr())
 
 
-class ShardedQuery:
-    """fast=True uses the leaner collectives (query-sharded hash codes, all-gather into one tensor + device merge
-    kernel, reduce-scatter + sliced final network + all-gather for stage 2) whenever the batch divides evenly by
-    the world size and the backend offers them; otherwise -- and always with fast=False -- the plain
-    all-gather / all-reduce forms are used.  Both give identical results."""
+class _Lane:
+    """Buffers + stream of one in-flight batch.  Everything is allocated once per batch size: no per-step tensors."""
 
-    def __init__(self, ix_or_engine, dist=None, group=None, fast=True):
-        self.eng = ix_or_engine if hasattr(ix_or_engine, "stage1_local") else HipEngine(ix_or_engine)
+    def __init__(self, stream):
+        self.stream, self.shape, self.busy, self.event = stream, None, False, None
+
+    def ensure(self, eng, y, G, qs):
+        Q = y.shape[0]
+        key = (Q, G, qs, y.device, y.dtype)
+        if self.shape == key:
+            return
+        k, T, K1w, W2 = eng.k, eng.T, (eng.k + 1) * eng.key_words, eng.Lc2 - eng.k
+        Qp, i32, i64, ft = qs * G, torch.int32, torch.int64, eng.ft
+        e = lambda shape, dt: eng.empty(shape, dt, y)  # noqa: E731
+        self.codes_slice, self.codes_all = e((qs * T,), i32), e((Qp * T,), i32)
+        self.keys, self.keys_in = e((Qp, K1w), i64), e((Qp, K1w), i64)
+        self.nvalid, self.nown = e((Q,), i32), e((Q,), i32)
+        self.top_i, self.top_d, self.top_all = e((qs, k), i32), e((qs, k), ft), e((Qp, k), i32)
+        self.s2, self.s2_in = e((Qp, W2), ft), e((Qp, W2), ft)
+        self.flagged = e((Q + 1,), i32)
+        es = 4 if ft == torch.float32 else 8
+        self.nb_d, self.nb_i = qs * k * es, qs * k * 4
+        per = (self.nb_d + self.nb_i + 15) // 16 * 16             # this rank's results: distances, then ids, padded
+        self.pack, self.pack_all = e((per,), torch.uint8), e((G, per), torch.uint8)
+        self.out_d_slice = self.pack[: self.nb_d].view(ft).view(qs, k)
+        self.out_i_slice = self.pack[self.nb_d: self.nb_d + self.nb_i].view(i32).view(qs, k)
+        self.out_i, self.out_d = e((Qp, k), i32), e((Qp, k), ft)
+        self.shape = key
+
+
+class ShardedQuery:
+    """query(y) = collect(submit(y)).  With submit()/collect() up to `lanes` batches are in flight.
+
+    exchange: "alltoall" (default), "allgather" (fallback: every rank receives everything and keeps its slice), or None =
+    ANN_SHARD_EXCHANGE from the environment, else probe all_to_all_single at start-up and agree across ranks."""
+
+    def __init__(self, ix_or_engine, dist=None, group=None, exchange=None, lanes=2, exact_all=None):
+        self.eng = ix_or_engine if hasattr(ix_or_engine, "sh_stage1") else HipEngine(ix_or_engine)
         self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size(group) > 1) else None
         self.group = group
         self.world = self.dist.get_world_size(group) if self.dist else 1
         self.rank = self.dist.get_rank(group) if self.dist else 0
         backend = self.dist.get_backend(group) if self.dist else None
-        self._stage_via_cpu = backend == "gloo"
-        self.fast = bool(fast and self.dist and backend != "gloo" and hasattr(self.dist, "all_gather_into_tensor")
-                         and hasattr(self.dist, "reduce_scatter_tensor"))
+        self._via_cpu = backend == "gloo"   # gloo moves host tensors: device tensors are staged through the host
+        self.exact_all = bool(os.environ.get("ANN_HIP_EXACT")) if exact_all is None else exact_all
+        if self.eng.k > self.eng.P1:
+            self.exact_all = True           # the selection cannot be proven when k exceeds the sorted prefix (Q1)
+        self.exchange = self._agree_exchange(exchange or os.environ.get("ANN_SHARD_EXCHANGE"))
+        self._lanes = [_Lane(None) for _ in range(max(1, lanes))]
+        self._next, self._tickets = 0, {}
         self.last_exact = 0
 
-    # -- collectives (RCCL on device tensors; gloo stages device tensors through the host) --
-    def _all_gather(self, t):
+    # ------------------------------------------------------------------ collectives
+    def _agree_exchange(self, want):
         if not self.dist:
-            return [t]
-        src = t.cpu() if (self._stage_via_cpu and t.is_cuda) else t
-        outs = [torch.empty_like(src) for _ in range(self.world)]
-        self.dist.all_gather(outs, src.contiguous(), group=self.group)
-        return [o.to(t.device) for o in outs] if src is not t else outs
+            return "none"
+        if want in ("alltoall", "allgather"):
+            return want
+        ok = 1
+        try:  # a tiny all-to-all on the backend's native tensors; an unsupported op raises on every rank alike
+            dev = "cpu" if (self._via_cpu or not torch.cuda.is_available()) else torch.device("cuda", torch.cuda.current_device())
+            a = torch.arange(self.world, dtype=torch.int64, device=dev) + 100 * self.rank
+            b = torch.empty_like(a)
+            self.dist.all_to_all_single(b, a, group=self.group)
+            if b.cpu().tolist() != [100 * g + self.rank for g in range(self.world)]:
+                ok = 0
+        except Exception:  # noqa: BLE001
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN, group=self.group)   # every rank takes the same branch
+        return "alltoall" if int(flag.cpu()[0]) == 1 else "allgather"
 
-    def _gather_stacked(self, t):
-        """[world, *t.shape] through one all-gather into a single tensor."""
-        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        self.dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
-        return out
+    def _host(self, t):
+        return t.cpu() if (self._via_cpu and t.is_cuda) else t
+
+    def _gather_cat(self, out, inp):
+        """out[g*rows:(g+1)*rows] = rank g's inp (concatenation along dim 0; out is contiguous)."""
+        if not self.dist:
+            out.copy_(inp.reshape(out.shape))
+            return
+        if self._via_cpu and inp.is_cuda:
+            o = torch.empty(out.shape, dtype=out.dtype)
+            self.dist.all_gather_into_tensor(o, inp.cpu().contiguous(), group=self.group)
+            out.copy_(o)
+        else:
+            self.dist.all_gather_into_tensor(out, inp, group=self.group)
+
+    def _to_owner(self, out, inp):
+        """inp = [G*qs, w]: rows [g*qs,(g+1)*qs) are for owner g.  out = [G*qs, w]: rows [g*qs,(g+1)*qs) = what rank g
+        computed for MY queries."""
+        if not self.dist:
+            out.copy_(inp)
+            return
+        G, r = self.world, self.rank
+        qs = inp.shape[0] // G
+        src = self._host(inp)
+        dst = torch.empty(out.shape, dtype=out.dtype) if src is not inp else out
+        if self.exchange == "alltoall":
+            self.dist.all_to_all_single(dst, src, group=self.group)
+        else:
+            everything = torch.empty((G * inp.shape[0],) + tuple(inp.shape[1:]), dtype=inp.dtype, device=src.device)
+            self.dist.all_gather_into_tensor(everything, src, group=self.group)
+            dst.copy_(everything.view(G, G, qs, -1)[:, r].reshape(dst.shape))
+        if dst is not out:
+            out.copy_(dst)
 
     def _all_min(self, t):
         if not self.dist:
             return t
-        if self._stage_via_cpu and t.is_cuda:
+        if self._via_cpu and t.is_cuda:
             c = t.cpu()
             self.dist.all_reduce(c, op=self.dist.ReduceOp.MIN, group=self.group)
             t.copy_(c)
@@ -131,60 +227,78 @@ class ShardedQuery:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
         return t
 
-    def _merge(self, cd, ci):
-        """Global k+1 smallest (dist,id) keys per query from every rank's k+1 (ids are disjoint across ranks)."""
-        if not self.dist:
-            return cd, ci
-        if self.fast and hasattr(self.eng, "merge") and self.world <= 16:
-            return self.eng.merge(self.world, self._gather_stacked(cd), self._gather_stacked(ci))
-        K1 = cd.shape[1]
-        if cd.dtype == torch.float32:  # one 64-bit key per candidate, one all-gather, one sort
-            key = (cd.view(torch.int32).to(torch.int64) << 32) | _u32(ci)
-            allk = torch.cat(self._all_gather(key), dim=1)
-            best = torch.sort(allk, dim=1).values[:, :K1]
-            md = (best >> 32).to(torch.int32).view(torch.float32)
-            mi = (best & 0xFFFFFFFF).to(torch.int32)
-            return md.contiguous(), mi.contiguous()
-        alld = torch.cat(self._all_gather(cd), dim=1)
-        alli = torch.cat(self._all_gather(ci), dim=1)
-        o1 = torch.sort(_u32(alli), dim=1, stable=True).indices           # secondary key: id
-        d1 = torch.gather(alld, 1, o1).view(torch.int64)                  # non-negative doubles order like int64
-        o2 = torch.sort(d1, dim=1, stable=True).indices[:, :K1]           # primary key: distance bits
-        sel = torch.gather(o1, 1, o2)
-        return torch.gather(alld, 1, sel).contiguous(), torch.gather(alli, 1, sel).contiguous()
+    # ------------------------------------------------------------------ one step
+    def submit(self, y, alias=False):
+        """Enqueue one batch (y: [Q,d], identical on every rank).  Returns a ticket for collect()."""
+        e, G, r = self.eng, self.world, self.rank
+        L = self._lanes[self._next % len(self._lanes)]
+        if L.busy:
+            raise RuntimeError("every lane is in flight: collect() the oldest ticket first")
+        if L.stream is None and y.is_cuda:
+            L.stream = e.new_stream(y.device)
+        Q = y.shape[0]
+        qs = (Q + G - 1) // G
+        q_lo = r * qs
+        if L.stream is not None:
+            L.stream.wait_stream(torch.cuda.current_stream(y.device))   # y was produced on the caller's stream
+        with e.use(L.stream):
+            L.ensure(e, y, G, qs)
+            e.sh_codes(y, q_lo, q_lo + qs, L.codes_slice)
+            self._gather_cat(L.codes_all, L.codes_slice)
+            if self.exact_all:
+                L.top_all.fill_(ID_FLAG - (1 << 32))                     # every query takes the exact path
+                L.top_i.fill_(ID_FLAG - (1 << 32))
+            else:
+                e.sh_stage1(y, alias, L.codes_all, L.keys, L.nvalid, L.nown)
+                self._to_owner(L.keys_in, L.keys)
+                e.sh_merge_finalize(G, Q, q_lo, qs, L.keys_in, L.nvalid, L.top_i, L.top_d)
+                self._gather_cat(L.top_all, L.top_i)
+            e.sh_stage2(y, alias, L.top_all, L.s2, L.flagged)
+            self._to_owner(L.s2_in, L.s2)
+            e.sh_final(G, Q, q_lo, qs, L.top_i, L.top_d, L.s2_in, L.out_i_slice, L.out_d_slice)
+            self._gather_cat(L.pack_all, L.pack.view(1, -1))
+            L.out_d.view(G, qs * e.k).copy_(L.pack_all[:, : L.nb_d].view(e.ft))
+            L.out_i.view(G, qs * e.k).copy_(L.pack_all[:, L.nb_d: L.nb_d + L.nb_i].view(torch.int32))
+            if L.stream is not None:
+                L.event = torch.cuda.Event()
+                L.event.record(L.stream)
+        L.busy, L.y, L.alias, L.Q = True, y, alias, Q
+        t = self._next
+        self._tickets[t] = L
+        self._next += 1
+        return t
+
+    def collect(self, ticket):
+        """Wait for the batch, repair flagged queries if there are any, return (ids int64 [Q,k], sq. distances [Q,k])."""
+        e = self.eng
+        L = self._tickets.pop(ticket)
+        if L.event is not None:
+            L.event.synchronize()
+        nf = int(L.flagged[:1].cpu()[0])      # the one host read-back of the step; identical on every rank
+        self.last_exact = nf
+        with e.use(L.stream):
+            if nf:
+                self._repair(L, nf)
+            Q = L.Q
+            ids, dd = _u32(L.out_i[:Q]), L.out_d[:Q].clone()
+            if L.stream is not None:
+                torch.cuda.current_stream(L.y.device).wait_stream(L.stream)
+        L.busy, L.y = False, None
+        return ids, dd
+
+    def _repair(self, L, nf):
+        """Exact path for the flagged queries, on every rank alike: full distance rows of the first Lc1 slots, MIN
+        all-reduce, the literal network; then their stage-2 rows the same way; the result rows are patched."""
+        e, y, alias = self.eng, L.y, L.alias
+        fl = torch.sort(_u32(L.flagged[1:1 + nf])).values.to(torch.int32)   # appended by atomics: sort => same order everywhere
+        top_d_all = e.empty(tuple(L.top_all.shape), e.ft, y)
+        ids1, dd1 = e.stage1_rows(y, alias, L.codes_all, fl)
+        self._all_min(dd1)
+        e.exact_select(1, ids1, dd1, fl, L.top_all, top_d_all)
+        ids2, dd2 = e.stage2_rows_list(y, alias, fl, L.top_all, top_d_all)
+        self._all_min(dd2)
+        e.exact_select(2, ids2, dd2, fl, L.out_i, L.out_d)
 
     def query(self, y, alias=False):
         """y: [Q,d] (identical on every rank).  Returns (ids int64 [Q,k], squared distances [Q,k])."""
-        e, G, r = self.eng, self.world, self.rank
-        Q = y.shape[0]
-        even = self.fast and Q % G == 0 and Q >= G
-        qs = Q // G if even else Q
-        # hash codes: every rank needs all of them (Q2 scramble), each computes one slice of the batch
-        if even:
-            codes = self._gather_stacked(e.codes(y[r * qs:(r + 1) * qs].contiguous())).reshape(-1)
-        else:
-            codes = e.codes(y)
-        cd, ci, nv = e.stage1_local(y, alias, codes)
-        cd, ci = self._merge(cd, ci)
-        top_i, top_d, flagged = e.finalize(cd, ci, nv)
-        self.last_exact = int(flagged.shape[0])
-        if flagged.shape[0]:  # identical list on every rank: it is a function of the merged candidates only
-            ids, dd = e.stage1_rows(y, alias, codes, flagged)
-            self._all_min(dd)
-            e.exact_select(1, ids, dd, flagged, top_i, top_d)
-        ids2, dd2 = e.stage2_rows(y, alias, top_i, top_d)
-        if even:
-            # each rank min-reduces and sorts only its slice of the queries, then the results are all-gathered
-            mine = torch.empty((qs, dd2.shape[1]), dtype=dd2.dtype, device=dd2.device)
-            self.dist.reduce_scatter_tensor(mine, dd2, op=self.dist.ReduceOp.MIN, group=self.group)
-            loc_i = torch.empty((qs, top_i.shape[1]), dtype=top_i.dtype, device=top_i.device)
-            loc_d = torch.empty((qs, top_d.shape[1]), dtype=top_d.dtype, device=top_d.device)
-            e.exact_select(2, ids2[r * qs:(r + 1) * qs].contiguous(), mine, None, loc_i, loc_d)
-            out_i = self._gather_stacked(loc_i).reshape(Q, -1)
-            out_d = self._gather_stacked(loc_d).reshape(Q, -1)
-        else:
-            self._all_min(dd2)
-            out_i = torch.empty_like(top_i)
-            out_d = torch.empty_like(top_d)
-            e.exact_select(2, ids2, dd2, None, out_i, out_d)
-        return _u32(out_i), out_d
+        return self.collect(self.submit(y, alias))

@@ -4,20 +4,27 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[2], "cfg3"): N=10M points, d=128, k=10, tries=10, float, Q=10k queries per
-GPU per step, synthetic N(0,1) data generated on the device (no dataset exists for this path).  One step =
-one query() batch: hash codes -> candidate gather + squared L2 + top-k selection (+ exact fallback) ->
+Workload (BASELINE.json configs[2], "cfg3"): N=10M points, d=128, k=10, tries=10, float, Q=10k queries per GPU per
+step.  Data: iid N(0,1) by Box-Muller on libc random() seeded with --seed -- the reference drivers' own stream
+(time_results.c:10-13,94,103; randNorm.c:9-21): points first, then precomp's rotation draws, then one draw per query
+batch.  --data randn uses torch.randn on the device instead (same distribution, seconds faster).
+One step = one query() batch: hash codes -> candidate gather + squared L2 + top-k selection (+ exact fallback) ->
 neighbour-of-neighbour refinement -> ids/distances, inputs and index resident in HBM.
 
-N > 1: the point rows are sharded across the ranks (each GPU gathers only rows it owns), per-shard top-(k+1)
-candidates are all-gathered over RCCL and merged, stage-2 distance rows are min-all-reduced.  The batch grows
-with N (Q = 10k x N queries per step, every rank sees all of them), so per-GPU gather work stays fixed:
-"scaling": "weak".  value = total queries / max-over-ranks time.
+N > 1: the point rows are sharded across the ranks (each GPU gathers only rows it owns); per-shard top-(k+1)
+candidates travel to each query's owner rank by an RCCL all-to-all over xGMI and are merged there, the owners' top-k
+ids are all-gathered, partial stage-2 rows go back to the owners the same way, results are all-gathered
+(approximatenn_amd/sharded.py).  The batch grows with N (Q = 10k x N queries per step, every rank sees all of them),
+so per-GPU gather work stays fixed: "scaling": "weak".  value = total queries / max-over-ranks time.  The extra object
+"strong" reports the same job with the batch FIXED at 10k queries in total.
 
 The JSON line also carries
   roofline     : the dominant kernel (stage1_select) priced at its ALGORITHMIC bytes / HIP-event duration
-  cpu_baseline : the oracle (CPU restatement, 1 core) timed on a bounded sample of the same workload on the
-                 same index, on rank 0 at N=1 only -- and its results are compared with the GPU's (parity).
+  cpu_baseline : the reference's own query_cpu (oracle/_ref) or the oracle (CPU restatement), 1 core, timed on a bounded
+                 sample of the same workload on the same index, on rank 0 at N=1 only -- and compared with the GPU's
+                 results (parity).
+  host_api     : the same workload through the reference's host-pointer ABI (query_gpu, ann.h:61-62) and through the
+                 pipelined host API (annhip_stream_*), PCIe included -- reported beside `value`, never as `value`.
 """
 import argparse
 import ctypes
@@ -43,6 +50,9 @@ def parse():
     ap.add_argument("--tries", type=int, default=10)
     ap.add_argument("--queries", dest="q", type=int, default=10_000, help="queries per GPU per step")
     ap.add_argument("--seed", type=int, default=12345)
+    ap.add_argument("--data", choices=["randnorm", "randn"], default="randnorm",
+                    help="randnorm = the reference drivers' Box-Muller stream on libc random() (host, ~20 s for cfg3's "
+                         "points); randn = torch.randn on the device")
     ap.add_argument("--streams", type=int, default=1,
                     help="single GPU: 1 = strictly serial steps (default; per-launch kernel times are meaningful); "
                          "N > 1 = independent batches alternate over N HIP streams/workspaces, so the latency-bound tail "
@@ -51,12 +61,27 @@ def parse():
                     help="skip the extra 2-stream throughput measurement reported under 'overlap'")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32", help="f64 = the reference's stock double build")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-api", action="store_true", help="skip the host-pointer (query_gpu / annhip_stream) extra")
+    ap.add_argument("--no-strong-extra", action="store_true", help="N > 1: skip the fixed-batch (strong scaling) extra")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
 
 
+def describe(n, d, k, T, Q, dtype):
+    """Workload label built from the actual sizes; the cfgN tag only when they are BASELINE.json's."""
+    word = "float" if dtype == "f32" else "double"
+    tag = {(100_000, 32, 10, "f32"): "cfg1", (1_000_000, 64, 10, "f32"): "cfg2", (10_000_000, 128, 10, "f32"): "cfg3",
+           (40_000_000, 128, 10, "f32"): "cfg4", (10_000_000, 256, 100, "f64"): "cfg5"}.get((n, d, k, dtype))
+
+    def short(v):
+        return "%dM" % (v // 1_000_000) if v % 1_000_000 == 0 else "%dk" % (v // 1000) if v % 1000 == 0 else str(v)
+    return tag, "N=%s d=%d k=%d Q=%s %s" % (short(n), d, k, short(Q), word), \
+        "%sN=%d d=%d k=%d tries=%d Q=%d/step %s" % (tag + ": " if tag else "", n, d, k, T, Q, word)
+
+
 def main():
     args = parse()
+    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -83,21 +108,32 @@ def main():
     esz = 4 if args.dtype == "f32" else 8
     Q = args.q * world  # weak scaling: the batch grows with the number of shards
     libc = ctypes.CDLL("libc.so.6")
+    nbatches = args.warmup + args.steps
 
-    # ---- synthetic data + index (identical on every rank: same seeds, deterministic build)
-    gen = torch.Generator(device=device)
-    gen.manual_seed(args.seed)
-    points = torch.randn((n, d), device=device, dtype=tdt, generator=gen)
+    # ---- synthetic data + index (identical on every rank: same seed, deterministic build)
     libc.srandom(args.seed)
-    torch.cuda.synchronize()
+    host_pts = None
     t0 = time.time()
-    ix = A.Index.precomp(points, k, T)
+    if args.data == "randnorm":
+        host_pts = A.synth_randnorm(n * d, args.dtype, reset=True).reshape(n, d)   # time_results.c:94
+        points = torch.from_numpy(host_pts).to(device)
+    else:
+        gen = torch.Generator(device=device)
+        gen.manual_seed(args.seed)
+        points = torch.randn((n, d), device=device, dtype=tdt, generator=gen)
+    torch.cuda.synchronize()
+    datagen_s = time.time() - t0
+    t0 = time.time()
+    ix = A.Index.precomp(points, k, T)          # draws its rotations from the same random() stream (Q12)
     torch.cuda.synchronize()
     precomp_s = time.time() - t0
     ix.set_stream(torch.cuda.current_stream().cuda_stream)
-    batches = [torch.randn((Q, d), device=device, dtype=tdt, generator=gen)
-               for _ in range(args.warmup + args.steps)]
+    if args.data == "randnorm":                 # one genRand per batch, in order (time_results.c:103)
+        batches = [torch.from_numpy(A.synth_randnorm(Q * d, args.dtype).reshape(Q, d)).to(device) for _ in range(nbatches)]
+    else:
+        batches = [torch.randn((Q, d), device=device, dtype=tdt, generator=gen) for _ in range(nbatches)]
 
+    runner = None
     if world > 1:
         from approximatenn_amd.sharded import ShardedQuery
         lo, hi = (n * rank) // world, (n * (rank + 1)) // world
@@ -105,52 +141,56 @@ def main():
         ix.reshard(shard, lo, hi)
         del points
         torch.cuda.empty_cache()
-        runner = ShardedQuery(ix, dist)
-        try:  # the lean collectives (all_gather_into_tensor / reduce_scatter MIN) first; plain ones if RCCL objects
-            runner.query(batches[0])
-            torch.cuda.synchronize()
-        except Exception as exc:  # noqa: BLE001
-            if rank == 0:
-                print("bench: fast collectives failed (%r); using all_gather/all_reduce" % (exc,), file=sys.stderr)
-            runner = ShardedQuery(ix, dist, fast=False)
-        step = lambda y: runner.query(y)
+        runner = ShardedQuery(ix, dist, lanes=2)   # exchange agreed on by all ranks at start-up (all-to-all, else all-gather)
+
+        def run_steps(ys):                          # two batches in flight: exchanges of i under the gather of i+1
+            pend = None
+            for y in ys:
+                t = runner.submit(y)
+                if pend is not None:
+                    runner.collect(pend)
+                pend = t
+            if pend is not None:
+                runner.collect(pend)
     else:
         ns = max(1, args.streams)
         out_ids = [torch.empty((Q, k), dtype=torch.int64, device=device) for _ in range(ns)]
         out_d = [torch.empty((Q, k), dtype=tdt, device=device) for _ in range(ns)]
-        if ns == 1:
-            step = lambda y: ix.query(y, out_ids=out_ids[0], out_dists=out_d[0])
-        else:
-            lanes = [(ix.workspace(), torch.cuda.Stream(device=device)) for _ in range(ns)]
-            counter = [0]
+        lanes = [(ix.workspace(), torch.cuda.Stream(device=device)) for _ in range(ns)] if ns > 1 else None
 
-            def step(y):
-                j = counter[0] % ns
-                counter[0] += 1
-                ix.query(y, out_ids=out_ids[j], out_dists=out_d[j], ws=lanes[j][0], stream=lanes[j][1])
+        def run_steps(ys):
+            for i, y in enumerate(ys):
+                if ns == 1:
+                    ix.query(y, out_ids=out_ids[0], out_dists=out_d[0])
+                else:
+                    j = i % ns
+                    ix.query(y, out_ids=out_ids[j], out_dists=out_d[j], ws=lanes[j][0], stream=lanes[j][1])
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    for i in range(args.warmup):
-        step(batches[i])
+    def timed(ys):
+        """barrier + synchronize, run, synchronize + barrier; max over ranks."""
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(ys)
+        submit = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device="cpu" if shared_gpu else device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el, submit
+
+    run_steps(batches[:args.warmup])
     torch.cuda.synchronize()
     ix.stats(reset=True)
     ix.profile(os.environ.get("ANN_BENCH_NO_EVENTS") != "1")
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(batches[args.warmup + i])
-    submit_s = time.perf_counter() - t0  # host time to enqueue K steps (the path is asynchronous on one GPU)
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device if not shared_gpu else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed, submit_s = timed(batches[args.warmup:])
     st = ix.stats()
     stage_ms = ix.stage_ms() if world == 1 else None
     ix.profile(False)
@@ -166,42 +206,65 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
                 "rows_gathered_per_query": round(v1, 1)}
+    if world > 1:
+        roofline["note"] = "rank 0's kernel; with two batches in flight it overlaps the other batch's small kernels"
 
-    # PMC traffic cannot be read in-process; for the default workload it comes from the committed rocprofv3 passes
+    # PMC counters cannot be read in-process: for the default workload the figure is the committed rocprofv3 --pmc
+    # measurement of this same command (profiles/traffic.json says which run); any other workload reports null.
+    tag, wl_short, wl_long = describe(n, d, k, T, Q, args.dtype)
     try:
         tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         if world == 1 and (n, d, k, T, Q, args.dtype) == (10_000_000, 128, 10, 10, 10_000, "f32"):
             roofline["traffic"] = tr["traffic_bytes_per_launch"]
-            roofline["traffic_source"] = tr["source"]
+            roofline["traffic_source"] = "static, from the committed rocprofv3 --pmc passes: " + tr["source"]
     except (OSError, ValueError, KeyError):
         pass
 
     value = Q * args.steps / elapsed
-    line = {"metric": "queries/sec, N=10M d=128 k=10 Q=10k float (query(): hash + candidate gather + L2 + top-k + refine)",
+    line = {"metric": "queries/sec, %s (query(): hash + candidate gather + L2 + top-k + refine)" % wl_short,
             "value": round(value, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "%sN=%d d=%d k=%d tries=%d Q=%d/step float, randn points+queries"
-                       % ("cfg3: " if (n, d, k, args.q, args.dtype) == (10_000_000, 128, 10, 10_000, "f32") else "", n, d, k, T, Q),
-                       "points_sharding": "rows/%d" % world, "streams": (max(1, args.streams) if world == 1 else 1), "d_short": ix.d_short, "L1": ix.L1, "P1": ix.P1,
-                       "L2": ix.L2, "P2": ix.P2, "sum_par_maxes": ix.sum_pm, "precomp_s": round(precomp_s, 2),
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": wl_long,
+                       "data_generator": ("iid N(0,1), Box-Muller on libc random() -- the reference drivers' stream "
+                                          "(randNorm.c:9-21), srandom(%d)" % args.seed) if args.data == "randnorm"
+                       else "iid N(0,1), torch.randn on the device, seed %d" % args.seed,
+                       "points_sharding": "rows/%d" % world,
+                       "streams": (max(1, args.streams) if world == 1 else 2), "d_short": ix.d_short, "L1": ix.L1, "P1": ix.P1,
+                       "L2": ix.L2, "P2": ix.P2, "sum_par_maxes": ix.sum_pm, "datagen_s": round(datagen_s, 2),
+                       "precomp_s": round(precomp_s, 2),
                        "exact_path_queries_per_step": round(st["exact_queries"] / args.steps, 2),
                        "host_submit_ms_per_step": round(submit_s / args.steps * 1e3, 4)},
             "roofline": roofline}
     if stage_ms:
         line["config"]["stage_ms_per_step"] = {k_: round(v / args.steps, 4) for k_, v in stage_ms.items()}
+    if runner is not None:
+        line["config"]["exchange"] = runner.exchange
+        line["config"]["queries_per_step_total"] = Q
+
+    # ---- N > 1 extra: strong scaling -- the batch FIXED at --queries in total (10k), sharded the same way
+    if world > 1 and not args.no_strong_extra:
+        Qs = args.q
+        ys = [b[:Qs].contiguous() for b in batches]
+        run_steps(ys[:args.warmup])
+        el_s, _ = timed(ys[args.warmup:])
+        line["strong"] = {"queries_per_step_total": Qs, "value": round(Qs * args.steps / el_s, 1), "unit": "queries/s",
+                          "ms_per_step": round(el_s / args.steps * 1e3, 4),
+                          "note": "same job with the batch fixed at %d queries in total (results differ from the weak "
+                                  "run's: they depend on the batch, SURVEY Q2)" % Qs}
 
     # ---- extra: the same K steps with consecutive batches overlapped on two streams (annhip_query_on); reported
     #      beside `value`, never instead of it: per-launch kernel times are not meaningful while gathers overlap
     if world == 1 and rank == 0 and max(1, args.streams) == 1 and not args.no_overlap_extra:
-        lanes = [(ix.workspace(), torch.cuda.Stream(device=device)) for _ in range(2)]
+        lanes2 = [(ix.workspace(), torch.cuda.Stream(device=device)) for _ in range(2)]
         o_ids = [torch.empty((Q, k), dtype=torch.int64, device=device) for _ in range(2)]
         o_d = [torch.empty((Q, k), dtype=tdt, device=device) for _ in range(2)]
-        for i in range(args.warmup + args.steps):
+        for i in range(nbatches):
             if i == args.warmup:
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-            ix.query(batches[i], out_ids=o_ids[i % 2], out_dists=o_d[i % 2], ws=lanes[i % 2][0], stream=lanes[i % 2][1])
+            ix.query(batches[i], out_ids=o_ids[i % 2], out_dists=o_d[i % 2], ws=lanes2[i % 2][0], stream=lanes2[i % 2][1])
         torch.cuda.synchronize()
         dt = time.perf_counter() - t1
         line["overlap"] = {"streams": 2, "value": round(Q * args.steps / dt, 1), "unit": "queries/s",
@@ -214,9 +277,16 @@ def main():
         rk = A.recall_ranks(points, batches[0][:qs].contiguous(), g_ids)
         line["config"]["recall_sample"] = {kk: round(v, 4) for kk, v in A.recall_summary(rk, k).items()}
         line["config"]["recall_sample"]["queries"] = qs
-    # ---- CPU baseline + full-size parity sample (rank 0, single GPU only)
-    if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(args, ix, points, batches[0], libc)
+    # ---- host-pointer API + CPU baseline share one exported save_t and one host copy of the points
+    if world == 1 and rank == 0 and not (args.no_cpu_baseline and args.no_host_api):
+        if host_pts is None:
+            host_pts = points.cpu().numpy()
+        save = ix.export()
+        if not args.no_host_api:
+            line["host_api"] = host_api(args, ix, save, host_pts, batches, np, torch, A)
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, ix, save, host_pts, batches[0], np, torch)
+        save.free()
     if rank == 0:
         print(json.dumps(line), flush=True)
     ix.close()
@@ -224,19 +294,49 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, ix, points, y_dev, libc):
+def host_api(args, ix, save, host_pts, batches, np, torch, A):
+    """The metric's workload through the reference's own ABI: query(save, points, ycnt, y, &dists) with HOST pointers
+    in and malloc'd host arrays out (ann.h:61-62, timed like time_results.c:104-109: around the call only), warm
+    residency cache, the cold first call apart; and the same batches through annhip_stream_* (3 lanes, pinned staging)."""
+    Q, k = batches[0].shape[0], ix.k
+    hy = [np.ascontiguousarray(b.cpu().numpy()) for b in batches[: max(4, min(len(batches), 10))]]
+    lib = A._lib.load(args.dtype)
+    lib.annhip_cache_clear()
+    t0 = time.perf_counter()
+    ids0, dd0 = A.query(save, host_pts, hy[0])          # cold: uploads points, tables, graph
+    cold = time.perf_counter() - t0
+    g_ids, g_d, _ = ix.query(batches[0])
+    torch.cuda.synchronize()
+    same = bool(np.array_equal(g_ids.cpu().numpy().astype(np.uint64), ids0) and
+                np.array_equal(g_d.cpu().numpy().view(np.uint8), dd0.view(np.uint8)))
+    A.query(save, host_pts, hy[1])
+    t0 = time.perf_counter()
+    for y in hy[1:]:
+        A.query(save, host_pts, y)
+    warm = (time.perf_counter() - t0) / (len(hy) - 1)
+    lib.annhip_cache_clear()
+    hs = ix.host_stream(Q, lanes=3)
+    reps = hy * 3
+    for _ in hs.map(hy[:3]):
+        pass
+    t0 = time.perf_counter()
+    for _ in hs.map(reps):
+        pass
+    piped = (time.perf_counter() - t0) / len(reps)
+    hs.close()
+    return {"query_gpu": {"value": round(Q / warm, 1), "unit": "queries/s", "ms_per_call": round(warm * 1e3, 4),
+                          "cold_first_call_s": round(cold, 3), "same_results_as_resident_path": same},
+            "stream_3_lanes": {"value": round(Q / piped, 1), "unit": "queries/s", "ms_per_batch": round(piped * 1e3, 4)},
+            "note": "host pointers in, host arrays out, PCIe included; never `value`"}
+
+
+def cpu_baseline(args, ix, save, host_pts, y_dev, np, torch):
     """CPU column on the GPU box's host cores, single thread, on a bounded sample of the same batch and the same
     (GPU-built) index, with the results compared against the GPU's.  kind = "reference": the reference's own query_cpu
     (oracle/_ref, compiled from /root/reference in the authoring container; it materialises Q*L1*d values, so the
     sample is small); otherwise kind = "port": the oracle (oracle/ann_oracle.c).  The oracle's rate is reported too."""
-    import numpy as np
-    import torch
-
     from oracle import oracle_py as O
-    save = ix.export()
     arrays = save.to_dict()
-    save.free()
-    host_pts = points.cpu().numpy()
     npdt = np.float32 if args.dtype == "f32" else np.float64
 
     def timed(backend, qs):

@@ -99,42 +99,58 @@ long annhip_stream_submit(annhip_stream *st, size_t ycnt, const ftype *y_host, i
 int annhip_stream_collect(annhip_stream *st, long ticket, size_t *ids_host, ftype *dists_host);
 void annhip_stream_close(annhip_stream *st);
 
-/* ---- staged query, for point-sharded multi-GPU hosts -------------------------------------------- */
-/* 1. hash codes of the whole batch: codes_dev u32[ycnt*tries], layout [q*tries+t] (alg.c:462-492).     */
-void annhip_codes(annhip_index *ix, size_t ycnt, const ftype *y_dev, uint32_t *codes_dev);
-/* 2. this device's k+1 best distinct candidates per query among the rows it owns:
- *    cand_dist ftype[ycnt][k+1], cand_id u32[ycnt][k+1] (ascending, padded (+inf,0xFFFFFFFF));
- *    nvalid u32[ycnt] = valid slots in the sorted prefix on ANY device (identical on every device).       */
-void annhip_stage1_local(annhip_index *ix, size_t ycnt, const ftype *y_dev, int alias,
-                         const uint32_t *codes_dev, ftype *cand_dist_dev, uint32_t *cand_id_dev,
-                         uint32_t *nvalid_dev);
-/* 2b. merge: in_*_dev hold every device's stage-1 candidates as [ndev][ycnt][k+1] (what an all-gather into one
- *     tensor yields); out_*_dev receive the k+1 globally smallest per query, same format. ndev <= 16.        */
-void annhip_merge_candidates(annhip_index *ix, int ndev, size_t ycnt, const ftype *in_dist_dev,
-                             const uint32_t *in_id_dev, ftype *out_dist_dev, uint32_t *out_id_dev);
-/* 3. after the caller merged all devices' candidates into the k+1 globally best (same format):
- *    writes top_id u32[ycnt][k]/top_dist and the list of queries that need the exact path.
- *    Returns their count (synchronises). flagged_dev must hold ycnt entries; the list is ascending, so it is
- *    identical on every device of a sharded host.                                                        */
-long annhip_stage1_finalize(annhip_index *ix, size_t ycnt, const ftype *cand_dist_dev,
-                            const uint32_t *cand_id_dev, const uint32_t *nvalid_dev,
-                            uint32_t *top_id_dev, ftype *top_dist_dev, uint32_t *flagged_dev);
-/* 4. exact path, part 1: ids u32[nq][Lc1] and distances ftype[nq][Lc1] of the first Lc1 slots of the
- *    queries listed in qidx_dev (NULL = queries 0..nq-1); slots not owned here get +inf (min-reduce the
- *    distance rows across devices).                                                                       */
+/* ---- staged query, for point-sharded multi-GPU hosts (approximatenn_amd/sharded.py) ---------- */
+/* One process per GPU; device g owns point rows [row_lo,row_hi) (annhip_index_create / annhip_index_reshard), tables
+ * and graph are replicated.  Queries are dealt to OWNER devices in contiguous slices of qs = ceil(ycnt/G); the owner
+ * merges its queries' candidates and runs their networks.  The host puts one collective between consecutive calls
+ * (all-gather, all-to-all, all-gather, all-to-all, all-gather).  Every annhip_sh_* call is asynchronous on `hip_stream`
+ * (a hipStream_t) and uses caller-provided buffers only, so several batches can be in flight on several streams.
+ * "keys" are packed (squared distance bits, id) pairs of annhip_key_bytes() bytes each (8 for float, 16 for double). */
+size_t annhip_key_bytes(void);
+/* 0. hash codes of queries [q_lo,q_hi) of the batch: codes_slice_dev u32[(q-q_lo)*tries+t] (alg.c:462-492).  The
+ *    all-gather of the slices is the [q*tries+t] array of the whole batch that stage 1 reads as [t*ycnt+q] (Q2).
+ *    Only the codes stage 1 can read are computed (Q1). */
+void annhip_sh_codes(annhip_index *ix, void *hip_stream, size_t ycnt, const ftype *y_dev, size_t q_lo, size_t q_hi,
+                     uint32_t *codes_slice_dev);
+/* 1. stage 1 of ALL ycnt queries over the rows this device owns: keys_dev key[ycnt][k+1] = its k+1 smallest distinct
+ *    candidates per query, ascending, padded with (+inf, 0xFFFFFFFF); nvalid_dev u32[ycnt] = valid slots in the sorted
+ *    prefix on ANY device (identical everywhere); nown_dev u32[ycnt] = rows gathered here.  Needs k <= P1. */
+void annhip_sh_stage1(annhip_index *ix, void *hip_stream, size_t ycnt, const ftype *y_dev, int alias,
+                      const uint32_t *codes_dev, void *keys_dev, uint32_t *nvalid_dev, uint32_t *nown_dev);
+/* 2. owner of queries [q_lo, q_lo+qs): keys_in_dev key[ndev][qs][k+1] (what the all-to-all of step 1 delivers) ->
+ *    the k globally best, top_id_dev u32[qs][k] / top_dist_dev ftype[qs][k], if the selection proof holds; otherwise
+ *    top_id[.][0] = 0xFFFFFFFE ("flagged": exact ties between different ids, < k candidates).
+ *    Slots of queries >= ycnt (ragged last slice) are filled with padding.  ndev <= 16. */
+void annhip_sh_merge_finalize(annhip_index *ix, void *hip_stream, int ndev, size_t ycnt, size_t q_lo, size_t qs,
+                              const void *keys_in_dev, const uint32_t *nvalid_dev, uint32_t *top_id_dev,
+                              ftype *top_dist_dev);
+/* 3. every device, all queries: top_id_all_dev u32[>=ycnt][k] (the all-gather of step 2) -> dist_out_dev
+ *    ftype[ycnt][Lc2-k] = distances of the stage-2 slots k..Lc2-1 this device owns, +inf elsewhere (supercharge,
+ *    compute.cl:252-263 + compdists, alg.c:314-326).  Flagged queries are skipped and listed:
+ *    flagged_dev u32[1+ycnt] = {count, query indices in no particular order}. */
+void annhip_sh_stage2(annhip_index *ix, void *hip_stream, size_t ycnt, const ftype *y_dev, int alias,
+                      const uint32_t *top_id_all_dev, ftype *dist_out_dev, uint32_t *flagged_dev);
+/* 4. owner: dist_in_dev ftype[ndev][qs][Lc2-k] (the all-to-all of step 3), its own top_id/top_dist slices ->
+ *    min over devices, the reference's network + rdups + network on the stage-2 row (alg.c:224-230,327), first k
+ *    entries to out_id_dev u32[qs][k] / out_dist_dev ftype[qs][k] (flagged queries: 0xFFFFFFFE / +inf). */
+void annhip_sh_final(annhip_index *ix, void *hip_stream, int ndev, size_t ycnt, size_t q_lo, size_t qs,
+                     const uint32_t *top_id_dev, const ftype *top_dist_dev, const ftype *dist_in_dev,
+                     uint32_t *out_id_dev, ftype *out_dist_dev);
+/* Exact path, used for the flagged queries (on the index's stream, annhip_index_set_stream):
+ * ids u32[nq][Lc1] and distances ftype[nq][Lc1] of the first Lc1 stage-1 slots of the queries listed in qidx_dev
+ * (NULL = queries 0..nq-1); slots not owned here get +inf (MIN-reduce the distance rows across devices). */
 void annhip_stage1_rows(annhip_index *ix, size_t ycnt, const ftype *y_dev, int alias,
                         const uint32_t *codes_dev, const uint32_t *qidx_dev, size_t nq,
                         uint32_t *ids_dev, ftype *dist_dev);
-/* 5. stage-2 rows: ids u32[ycnt][Lc2], distances ftype[ycnt][Lc2] from the current top-k.                */
-void annhip_stage2_rows(annhip_index *ix, size_t ycnt, const ftype *y_dev, int alias,
-                        const uint32_t *top_id_dev, const ftype *top_dist_dev, uint32_t *ids_dev,
-                        ftype *dist_dev);
-/* 6. the reference's network+rdups+network on rows of reference length L (stage: 1 -> L1, 2 -> L2),
- *    first k entries to out_id u32[.][k] / out_dist at row qidx_dev[i] (NULL = i).                        */
+/* stage-2 rows of the listed queries: ids u32[nq][Lc2], distances ftype[nq][Lc2] from top_id_dev u32[ycnt][k] /
+ * top_dist_dev ftype[ycnt][k] (rows indexed by query). */
+void annhip_stage2_rows_list(annhip_index *ix, size_t ycnt, const ftype *y_dev, int alias, const uint32_t *qidx_dev,
+                             size_t nq, const uint32_t *top_id_dev, const ftype *top_dist_dev, uint32_t *ids_dev,
+                             ftype *dist_dev);
+/* the reference's network+rdups+network on rows of reference length L (stage: 1 -> L1, 2 -> L2),
+ * first k entries to out_id u32[.][k] / out_dist at row qidx_dev[i] (NULL = i). */
 void annhip_exact_select(annhip_index *ix, int stage, size_t nq, uint32_t *ids_dev, ftype *dist_dev,
                          const uint32_t *qidx_dev, uint32_t *out_id_dev, ftype *out_dist_dev);
-/* u32 -> size_t on the device */
-void annhip_widen_ids(annhip_index *ix, size_t count, const uint32_t *in_dev, size_t *out_dev);
 
 /* ---- recall scoring (counterpart of /root/reference/test_correctness.c:169-262) --------------- */
 /* ranks_dev[q][j] (u64) = number of the n points strictly closer to query q than its j-th guessed neighbour, by one

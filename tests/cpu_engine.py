@@ -1,9 +1,11 @@
 """A CPU stand-in for approximatenn_amd.sharded.HipEngine, built on the oracle -- TEST INFRASTRUCTURE.
 
-It implements the staged per-shard steps (include/ann_hip.h) in numpy + oracle calls so that the multi-rank
-orchestration in approximatenn_amd/sharded.py (exchanges, merge, fallback) can run under gloo without a GPU.
-It restates the per-shard kernels' contracts, not their code.
+It implements the staged per-shard steps (include/ann_hip.h: annhip_sh_* and the exact-path calls) in numpy + oracle
+calls so that the multi-rank orchestration in approximatenn_amd/sharded.py (owner protocol, exchanges, repair) can run
+under gloo without a GPU.  It restates the per-shard kernels' contracts, not their code.
 """
+import contextlib
+
 import numpy as np
 import torch
 
@@ -67,7 +69,127 @@ class CpuShardEngine:
     def _own(self, pid):
         return self.lo <= pid < self.hi
 
-    # ---- HipEngine interface
+    # ---- HipEngine interface: lanes and buffers
+    key_words = property(lambda self: 1 if self.prec == "f32" else 2)
+
+    def new_stream(self, device):
+        return None
+
+    def use(self, stream):
+        return contextlib.nullcontext()
+
+    def empty(self, shape, dtype, like):
+        return torch.empty(shape, dtype=dtype)
+
+    def _bits(self, dv):
+        return int(np.array(dv, dtype=self.npft).view(np.uint32 if self.prec == "f32" else np.uint64))
+
+    # ---- owner protocol (annhip_sh_*)
+    def sh_codes(self, y, q_lo, q_hi, out):
+        Q = y.shape[0]
+        c = self.orc.query_codes(self.hs, y.numpy()).astype(np.uint32)        # [q*T+t] for the whole batch
+        hi = min(q_hi, Q)
+        if hi > q_lo:
+            out.numpy().view(np.uint32)[: (hi - q_lo) * self.T] = c[q_lo * self.T: hi * self.T]
+
+    def sh_stage1(self, y, alias, codes, keys, nvalid, nown):
+        Q, K1, kw = y.shape[0], self.k + 1, self.key_words
+        cd, ci, nv = self.stage1_local(y, alias, codes)
+        cdn, cin = cd.numpy(), ci.numpy().view(np.uint32)
+        kk = keys.numpy().view(np.uint64)
+        for x in range(Q):
+            for t in range(K1):
+                b = self._bits(cdn[x, t])
+                if kw == 1:
+                    kk[x, t] = (b << 32) | int(cin[x, t])
+                else:
+                    kk[x, 2 * t], kk[x, 2 * t + 1] = b, int(cin[x, t])
+        nvalid.numpy()[:] = nv.numpy()
+        nown.numpy()[:] = 0
+
+    def _unpack(self, row, t):
+        if self.key_words == 1:
+            v = int(row[t])
+            return v >> 32, v & 0xFFFFFFFF
+        return int(row[2 * t]), int(row[2 * t + 1])
+
+    def sh_merge_finalize(self, G, Q, q_lo, qs, keys_in, nvalid, top_i, top_d):
+        k, K1 = self.k, self.k + 1
+        kin = keys_in.numpy().view(np.uint64).reshape(G, qs, -1)
+        nvn = nvalid.numpy().view(np.uint32)
+        ti, td = top_i.numpy().view(np.uint32), top_d.numpy()
+        bt = np.uint32 if self.prec == "f32" else np.uint64
+        for xl in range(qs):
+            if q_lo + xl >= Q:
+                ti[xl], td[xl] = 0xFFFFFFFF, np.inf
+                continue
+            cand = []
+            for g in range(G):
+                for t in range(K1):
+                    b, i = self._unpack(kin[g, xl], t)
+                    if i != 0xFFFFFFFF:
+                        cand.append((b, i))
+            cand = sorted(cand)[:K1]
+            m = len(cand)
+            flag = k > self.P1 or m < k
+            if not flag:
+                dk = np.array([cand[k - 1][0]], dtype=bt).view(self.npft)[0]
+                flag = not np.isfinite(dk) or any(cand[t][0] == cand[t + 1][0] for t in range(m - 1)) \
+                    or (self.L1 > self.P1 and nvn[q_lo + xl] >= self.P1)
+            for t in range(min(k, m)):
+                ti[xl, t] = cand[t][1]
+                td[xl, t] = np.array([cand[t][0]], dtype=bt).view(self.npft)[0]
+            if flag:
+                ti[xl, 0] = 0xFFFFFFFE
+
+    def _stage2_id(self, ti_row, j):
+        k, n = self.k, self.n
+        parent, z = int(ti_row[j // k - 1]), j % k
+        return int(self.save["graph"][parent, z]) if parent < n else (int(self.save["graph"][0, z]) | n)
+
+    def sh_stage2(self, y, alias, top_all, dist_out, flagged):
+        Q, k = y.shape[0], self.k
+        yn, ta = y.numpy(), top_all.numpy().view(np.uint32)
+        do, fl = dist_out.numpy(), flagged.numpy().view(np.uint32)
+        fl[0] = 0
+        for x in range(Q):
+            if ta[x, 0] == 0xFFFFFFFE:
+                fl[1 + fl[0]] = x
+                fl[0] += 1
+                continue
+            for j in range(k, self.Lc2):
+                pid = self._stage2_id(ta[x], j)
+                do[x, j - k] = self._dist(yn[x], pid) if (self._ok(pid, x, alias) and self._own(pid)) else np.inf
+        if fl[0] > 1:   # the kernel appends with atomics in no particular order
+            fl[1:1 + fl[0]] = fl[1:1 + fl[0]][::-1].copy()
+
+    def sh_final(self, G, Q, q_lo, qs, top_i, top_d, dist_in, out_i, out_d):
+        k = self.k
+        ti, td = top_i.numpy().view(np.uint32), top_d.numpy()
+        din = dist_in.numpy().reshape(G, qs, -1)
+        oi, od = out_i.numpy().view(np.uint32), out_d.numpy()
+        for xl in range(qs):
+            if q_lo + xl >= Q or ti[xl, 0] == 0xFFFFFFFE:
+                oi[xl], od[xl] = (0xFFFFFFFF if q_lo + xl >= Q else 0xFFFFFFFE), np.inf
+                continue
+            rid = np.empty(self.Lc2, dtype=np.uint64)
+            rdd = np.empty(self.Lc2, dtype=self.npft)
+            rid[:k], rdd[:k] = ti[xl], td[xl]
+            for j in range(k, self.Lc2):
+                rid[j] = self._stage2_id(ti[xl], j) & 0xFFFFFFFF
+                rdd[j] = din[:, xl, j - k].min()
+            L = self.L2
+            rid = np.concatenate([rid, (1 << 40) + np.arange(L - self.Lc2, dtype=np.uint64)])
+            rdd = np.concatenate([rdd, np.full(L - self.Lc2, np.inf, dtype=self.npft)])
+            s_ids, s_d = self.orc.topk_stage(rid, rdd)
+            oi[xl], od[xl] = s_ids[:k].astype(np.uint32), s_d[:k]
+
+    def stage2_rows_list(self, y, alias, qidx, top_i, top_d):
+        ids, dd = self.stage2_rows(y, alias, top_i, top_d)
+        sel = torch.from_numpy(qidx.numpy().view(np.uint32).astype(np.int64))
+        return ids[sel].contiguous(), dd[sel].contiguous()
+
+    # ---- per-shard building blocks
     def codes(self, y):
         c = self.orc.query_codes(self.hs, y.numpy())
         return torch.from_numpy(c.astype(np.uint32).view(np.int32).copy())
@@ -91,26 +213,6 @@ class CpuShardEngine:
             for i, (_, pid, dv) in enumerate(sorted(keys)[:K1]):
                 cd[x, i], ci[x, i] = dv, pid
         return torch.from_numpy(cd), torch.from_numpy(ci.view(np.int32)), torch.from_numpy(nv.view(np.int32))
-
-    def finalize(self, cd, ci, nv):
-        k, K1 = self.k, self.k + 1
-        cdn, cin, nvn = cd.numpy(), ci.numpy().view(np.uint32), nv.numpy().view(np.uint32)
-        Q = cdn.shape[0]
-        top_i = np.zeros((Q, k), dtype=np.uint32)
-        top_d = np.zeros((Q, k), dtype=self.npft)
-        flagged = []
-        for x in range(Q):
-            m = int(np.sum(cin[x] != 0xFFFFFFFF))
-            flag = k > self.P1 or m < k
-            if not flag:
-                flag = not np.isfinite(cdn[x, k - 1]) or any(cdn[x, t] == cdn[x, t + 1] for t in range(m - 1)) \
-                    or (self.L1 > self.P1 and nvn[x] >= self.P1)
-            if flag:
-                flagged.append(x)
-            else:
-                top_i[x], top_d[x] = cin[x, :k], cdn[x, :k]
-        return (torch.from_numpy(top_i.view(np.int32)), torch.from_numpy(top_d),
-                torch.from_numpy(np.array(flagged, dtype=np.int32)))
 
     def stage1_rows(self, y, alias, codes, qidx):
         Q = y.shape[0]

@@ -30,6 +30,23 @@ def test_bench_line_contract():
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] == 1 and c["value"] > 0
     assert c["parity_on_sample"] == {"ids_bit_exact": True, "dists_bit_exact": True}
+    # labels come from the actual sizes, not from the default workload
+    assert "N=200k d=128 k=10 Q=2k float" in d["metric"] and "N=200000 d=128 k=10 tries=10 Q=2000/step float" in d["config"]["workload"]
+    assert "cfg" not in d["config"]["workload"] and r["traffic"] is None      # PMC traffic only for the profiled default
+    assert "random()" in d["config"]["data_generator"]
+    h = d["host_api"]   # the reference's host-pointer ABI, beside (never as) value
+    assert h["query_gpu"]["value"] > 0 and h["query_gpu"]["same_results_as_resident_path"] is True
+    assert h["stream_3_lanes"]["value"] > 0
+
+
+def test_bench_labels_follow_dtype_and_shape():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--points", "60000", "--dim", "64", "--knn", "12",
+                          "--queries", "500", "--steps", "2", "--warmup", "1", "--dtype", "f64", "--data", "randn",
+                          "--no-cpu-baseline", "--no-host-api"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip().startswith("{")][0])
+    assert d["dtype"] == "f64" and "N=60k d=64 k=12 Q=500 double" in d["metric"] and "double" in d["config"]["workload"]
+    assert "torch.randn" in d["config"]["data_generator"] and "cpu_baseline" not in d and "host_api" not in d
 
 
 def test_bench_multi_rank_branch_two_ranks_sharing_the_gpu():
@@ -46,4 +63,20 @@ def test_bench_multi_rank_branch_two_ranks_sharing_the_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["points_sharding"] == "rows/2" and "Q=2000/step" in d["config"]["workload"]
+    assert d["config"]["exchange"] == "alltoall" and d["config"]["queries_per_step_total"] == 2000
     assert "cpu_baseline" not in d          # rank 0 at N=1 only
+    s = d["strong"]                         # the same job with the batch fixed at --queries in total
+    assert s["queries_per_step_total"] == 1000 and s["value"] > 0
+
+
+def test_bench_multi_rank_fallback_exchange():
+    """ANN_SHARD_EXCHANGE=allgather: the exchange every rank falls back to, together, when all_to_all_single is not
+    available on the backend (decided collectively at start-up, sharded.py)."""
+    env = dict(os.environ, ANN_BENCH_SHARED_GPU="1", ANN_SHARD_EXCHANGE="allgather")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29634", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--points", "100000", "--queries", "500",
+           "--steps", "2", "--warmup", "1", "--data", "randn", "--no-strong-extra"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip().startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["config"]["exchange"] == "allgather" and "strong" not in d

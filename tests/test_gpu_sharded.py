@@ -16,6 +16,8 @@ pytestmark = pytest.mark.gpu
 
 
 class ThreadDist:
+    """The subset of torch.distributed that sharded.py uses, for G threads of one process sharing one GPU."""
+
     class ReduceOp:
         MIN = "min"
 
@@ -34,45 +36,38 @@ class ThreadDist:
     def get_rank(self, group=None):
         return self.tl.rank
 
-    def all_gather_into_tensor(self, out, t, group=None):
+    def _publish(self, t):
+        torch.cuda.current_stream().synchronize()   # producers ran on this thread's lane stream
         self.slots[self.tl.rank] = t
-        self.bar.wait()
-        out.copy_(torch.stack([s_ for s_ in self.slots]).reshape(out.shape))
-        torch.cuda.synchronize()
         self.bar.wait()
 
-    def reduce_scatter_tensor(self, out, t, op=None, group=None):
-        self.slots[self.tl.rank] = t
+    def _done(self):
+        torch.cuda.current_stream().synchronize()
         self.bar.wait()
+
+    def all_gather_into_tensor(self, out, t, group=None):
+        self._publish(t)
+        out.copy_(torch.cat([s_.reshape((-1,) + tuple(out.shape[1:])) for s_ in self.slots]).reshape(out.shape))
+        self._done()
+
+    def all_to_all_single(self, out, t, group=None):
+        self._publish(t)
+        n = t.shape[0] // self.world
+        r = self.tl.rank
+        out.copy_(torch.cat([s_[r * n:(r + 1) * n] for s_ in self.slots]))
+        self._done()
+
+    def all_reduce(self, t, op=None, group=None):
+        self._publish(t.clone())
         res = self.slots[0]
         for s_ in self.slots[1:]:
             res = torch.minimum(res, s_)
-        n = out.shape[0]
-        out.copy_(res[self.tl.rank * n:(self.tl.rank + 1) * n])
-        torch.cuda.synchronize()
-        self.bar.wait()
-
-    def all_gather(self, outs, t, group=None):
-        self.slots[self.tl.rank] = t
-        self.bar.wait()
-        for o, s in zip(outs, self.slots):
-            o.copy_(s)
-        torch.cuda.synchronize()
-        self.bar.wait()
-
-    def all_reduce(self, t, op=None, group=None):
-        self.slots[self.tl.rank] = t.clone()
-        self.bar.wait()
-        res = self.slots[0]
-        for s in self.slots[1:]:
-            res = torch.minimum(res, s)
-        torch.cuda.synchronize()
-        self.bar.wait()
+        self._done()
         t.copy_(res)
-        self.bar.wait()
+        self._done()
 
 
-def _run_sharded(prec, save_arrays, pts, y, world, alias=False, fast=True):
+def _run_sharded(prec, save_arrays, pts, y, world, alias=False, fast=True, pipelined=False):
     save = A.Save.from_dict(prec, save_arrays)
     td = ThreadDist(world)
     results, errors = [None] * world, []
@@ -83,9 +78,14 @@ def _run_sharded(prec, save_arrays, pts, y, world, alias=False, fast=True):
             td.tl.rank = rank
             lo, hi = (len(pts) * rank) // world, (len(pts) * (rank + 1)) // world
             ix = A.Index.from_save(save, torch.from_numpy(np.ascontiguousarray(pts[lo:hi])).cuda(), lo, hi)
-            sq = ShardedQuery(ix, td, fast=fast)
-            assert sq.fast == fast
-            ids, dd = sq.query(yt, alias=alias)
+            sq = ShardedQuery(ix, td, exchange="alltoall" if fast else "allgather")
+            if pipelined:    # two batches in flight on two HIP streams
+                t0, t1 = sq.submit(yt, alias=alias), sq.submit(yt, alias=alias)
+                ids, dd = sq.collect(t0)
+                ids1, dd1 = sq.collect(t1)
+                assert torch.equal(ids, ids1) and torch.equal(dd.view(torch.uint8), dd1.view(torch.uint8))
+            else:
+                ids, dd = sq.query(yt, alias=alias)
             torch.cuda.synchronize()
             results[rank] = (ids.cpu().numpy().astype(np.uint64), dd.cpu().numpy(), sq.last_exact)
             ix.close()
@@ -104,7 +104,7 @@ def _run_sharded(prec, save_arrays, pts, y, world, alias=False, fast=True):
                                         ("pow2_d32_f32", 4), ("k17_d100_f64", 2), ("few_candidates_f32", 2),
                                         ("pow2_d64_f32", 8)])
 def test_sharded_on_one_gpu_matches_golden(name, world, fast):
-    # Q divisible by the world size (fast collectives: sharded codes, device merge, reduce-scatter) and not
+    # owner protocol with the all-to-all exchange (fast) and with the all-gather fallback; Q divisible by the world size and not
     g = load_golden(name)
     for ids, dd, _ in _run_sharded(g["prec"], g["save"], g["points"], g["y"], world, fast=fast):
         assert np.array_equal(ids, g["query_ids"]) and bits_equal(dd, g["query_dists"])
@@ -150,3 +150,19 @@ def test_sharded_alias_query():
     qa = len(g["alias_ids"])
     for ids, dd, _ in _run_sharded("f32", g["save"], g["points"], g["points"][:qa], 2, alias=True):
         assert np.array_equal(ids, g["alias_ids"]) and bits_equal(dd, g["alias_dists"])
+
+
+@pytest.mark.parametrize("name,world", [("pow2_d128_f32", 4), ("k17_d100_f64", 3)])
+def test_two_batches_in_flight(name, world):
+    g = load_golden(name)
+    for ids, dd, _ in _run_sharded(g["prec"], g["save"], g["points"], g["y"], world, pipelined=True):
+        assert np.array_equal(ids, g["query_ids"]) and bits_equal(dd, g["query_dists"])
+
+
+def test_sharded_exact_everywhere(monkeypatch):
+    """ANN_HIP_EXACT=1: every query is flagged and goes through the repair pass (rows, MIN all-reduce, network)."""
+    monkeypatch.setenv("ANN_HIP_EXACT", "1")
+    A._lib.reload_env()
+    g = load_golden("pow2_d32_f32")
+    for ids, dd, nex in _run_sharded("f32", g["save"], g["points"], g["y"], 2):
+        assert np.array_equal(ids, g["query_ids"]) and bits_equal(dd, g["query_dists"]) and nex == len(g["y"])

@@ -34,10 +34,12 @@ def _tie_case():
     return pts, y, save, ids, dd
 
 
-def _worker(rank, world, port, case):
+def _worker(rank, world, port, case, mode="plain"):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        if mode != "plain":
+            return _worker_modes(rank, world, case, mode)
         if case == "ties":
             pts, y, save, want_ids, want_d = _tie_case()
             prec = "f32"
@@ -52,6 +54,65 @@ def _worker(rank, world, port, case):
         assert bits_equal(dd.numpy(), want_d), "rank %d dists" % rank
         if case == "ties":
             assert sq.last_exact > 0
+    finally:
+        dist.destroy_process_group()
+
+
+def _worker_modes(rank, world, case, mode):
+    g = load_golden(case)
+    pts, y, save, want_ids, want_d, prec = g["points"], g["y"], g["save"], g["query_ids"], g["query_dists"], g["prec"]
+    lo, hi = _bounds(len(pts), world, rank)
+    eng = CpuShardEngine(save, pts, lo, hi, prec)
+    yt = torch.from_numpy(np.ascontiguousarray(y))
+    if mode == "allgather":      # the fallback exchange: every rank receives everything and keeps its slice
+        sq = ShardedQuery(eng, dist, exchange="allgather")
+        assert sq.exchange == "allgather"
+        ids, dd = sq.query(yt)
+    elif mode == "exact":        # every query through the repair path (what k > P1 or ANN_HIP_EXACT selects)
+        sq = ShardedQuery(eng, dist, exact_all=True)
+        ids, dd = sq.query(yt)
+        assert sq.last_exact == len(y)
+    elif mode == "pipelined":    # two batches in flight; the second is a ragged prefix of the first's queries
+        sq = ShardedQuery(eng, dist, lanes=2)
+        assert sq.exchange == "alltoall"          # probed and agreed on at start-up
+        t0 = sq.submit(yt)
+        with pytest.raises(RuntimeError):
+            sq.submit(yt), sq.submit(yt)          # only two lanes
+        ids, dd = sq.collect(t0)
+        sq.collect(t0 + 1)
+    else:
+        raise AssertionError(mode)
+    assert np.array_equal(ids.numpy().astype(np.uint64), want_ids), "rank %d ids (%s)" % (rank, mode)
+    assert bits_equal(dd.numpy(), want_d), "rank %d dists (%s)" % (rank, mode)
+
+
+@pytest.mark.parametrize("world,case,mode", [(2, "tiny_appendixA_f32", "allgather"), (3, "few_candidates_f64", "allgather"),
+                                             (2, "odd_everything_f32", "exact"), (3, "tiny_appendixA_f32", "pipelined")])
+def test_sharded_query_modes(world, case, mode):
+    port = 29500 + (os.getpid() + hash((case, mode))) % 2000
+    mp.spawn(_worker, args=(world, port, case, mode), nprocs=world, join=True)
+
+
+def test_batch_not_divisible_by_world_size():
+    """Ragged owner slices (the last rank owns fewer queries, or none): Q = 7 over 3 ranks and Q = 2 over 3 ranks."""
+    port = 29500 + (os.getpid() + 777) % 2000
+    mp.spawn(_ragged_worker, args=(3, port), nprocs=3, join=True)
+
+
+def _ragged_worker(rank, world, port):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = load_golden("tiny_appendixA_f32")
+        orc = O.CpuBackend("f32", "oracle")
+        lo, hi = _bounds(len(g["points"]), world, rank)
+        eng = CpuShardEngine(g["save"], g["points"], lo, hi, "f32")
+        sq = ShardedQuery(eng, dist)
+        for Q in (7, 2):
+            y = np.ascontiguousarray(g["y"][:Q])
+            want_ids, want_d = orc.query(g["save"], g["points"], y)     # results depend on the batch (Q2): ask the oracle
+            ids, dd = sq.query(torch.from_numpy(y))
+            assert np.array_equal(ids.numpy().astype(np.uint64), want_ids) and bits_equal(dd.numpy(), want_d), (rank, Q)
     finally:
         dist.destroy_process_group()
 

@@ -1,89 +1,129 @@
-"""Time ONE rank's share of a G-way point-sharded query step on a SINGLE GPU.
+"""Time ONE rank's share of a G-way point-sharded query step on a SINGLE GPU (owner protocol, sharded.py).
 
 The index is re-sharded so that this device owns 1/G of the rows and the batch is G x 10k queries, exactly what
-rank 0 of a G-GPU node would execute; the collectives are loop-back stand-ins (the other ranks' candidates are
-padding), so RESULTS ARE MEANINGLESS and communication time is NOT included -- only the per-rank kernel work is
-representative.  Used to project scaling before a multi-GPU node is available.
+rank 0 of a G-GPU node would execute; the collectives are loop-back stand-ins (the other ranks' contributions are
+padding / copies), so RESULTS ARE MEANINGLESS and communication time is NOT included -- only the per-rank kernel work
+and the host-side orchestration are representative.  Used to project scaling before a multi-GPU node is available
+(DESIGN.md section 4).
 
-    python tools/emulate_rank.py
+    python tools/emulate_rank.py [--points N] [--queries Q_per_rank]
 """
-import ctypes, os, sys, time
+import argparse
+import ctypes
+import os
+import sys
+import time
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root
 import torch
+
 import approximatenn_amd as A
 from approximatenn_amd.sharded import ShardedQuery
 
+ap = argparse.ArgumentParser()
+ap.add_argument("--points", type=int, default=10_000_000)
+ap.add_argument("--queries", type=int, default=10_000)
+ap.add_argument("--worlds", type=str, default="1,2,4,8")
+args = ap.parse_args()
+
+
 class Loopback:
-    class ReduceOp: MIN = "min"
-    def __init__(self, world, rank): self.world, self.rank = world, rank
+    """Stand-in for torch.distributed: this process is rank 0 of `world`; nobody else exists."""
+
+    class ReduceOp:
+        MIN = "min"
+
+    def __init__(self, world):
+        self.world = world
+
     def is_initialized(self): return True
     def get_world_size(self, g=None): return self.world
-    def get_rank(self, g=None): return self.rank
+    def get_rank(self, g=None): return 0
     def get_backend(self, g=None): return "loopback"
-    def all_gather_into_tensor(self, out, t, group=None):
-        o = out.view(self.world, -1)
-        if t.dim() == 2 and t.shape[1] == 11:  # stage-1 candidates: the other ranks contribute padding, not copies
-            if t.dtype == torch.float32: o.fill_(float("inf"))
-            else: o.fill_(-1)
-            o[0].copy_(t.reshape(-1))
-        else:
-            o.copy_(t.reshape(1, -1).expand(self.world, -1))
-    def reduce_scatter_tensor(self, out, t, op=None, group=None):
-        n = out.shape[0]; out.copy_(t[self.rank * n:(self.rank + 1) * n])
-    def all_reduce(self, t, op=None, group=None): pass
-    def all_gather(self, outs, t, group=None):
-        for o in outs: o.copy_(t)
 
-n, d, k, T = 10_000_000, 128, 10, 10
+    def all_gather_into_tensor(self, out, t, group=None):   # every rank "contributed" what this one did
+        out.view(self.world, -1).copy_(t.reshape(1, -1).expand(self.world, -1))
+
+    def all_to_all_single(self, out, t, group=None):        # own part arrives; the peers' parts are padding
+        n = t.shape[0] // self.world
+        if t.dtype == torch.int64:
+            out.fill_((0x7F800000 << 32) | 0xFFFFFFFF)       # key(+inf, no id) of the float build
+        else:
+            out.fill_(float("inf"))
+        out[:n].copy_(t[:n])
+
+    def all_reduce(self, t, op=None, group=None): pass
+
+
+n, d, k, T = args.points, 128, 10, 10
 dev = torch.device("cuda", 0)
-gen = torch.Generator(device=dev); gen.manual_seed(12345)
+gen = torch.Generator(device=dev)
+gen.manual_seed(12345)
 points = torch.randn((n, d), device=dev, dtype=torch.float32, generator=gen)
 ctypes.CDLL("libc.so.6").srandom(12345)
 ix = A.Index.precomp(points, k, T)
-for G in (1, 2, 4, 8):
-    Q = 10_000 * G
-    ys = [torch.randn((Q, d), device=dev, dtype=torch.float32, generator=gen) for _ in range(6)]
+base = None
+for G in [int(g) for g in args.worlds.split(",")]:
+    Q = args.queries * G
+    ys = [torch.randn((Q, d), device=dev, dtype=torch.float32, generator=gen) for _ in range(8)]
     if G == 1:
-        run = lambda y: ix.query(y)
+        def run_all(batches):
+            for y in batches:
+                ix.query(y)
+        label = "annhip_query"
     else:
         lo, hi = 0, n // G
         ix.reshard(points[lo:hi], lo, hi)
-        sq = ShardedQuery(ix, Loopback(G, 0))
-        assert sq.fast
-        run = lambda y: sq.query(y)
-    run(ys[0]); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for y in ys[1:]: run(y)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / 5
-    print("G=%d  Q=%6d  per-rank step %.3f ms  -> %.2f M q/s aggregate (compute only), scaling %.2fx" % (G, Q, dt * 1e3, Q / dt / 1e6, (Q / dt) / (10_000 / 1.389e-3)))
+        sq = ShardedQuery(ix, Loopback(G), exchange="alltoall", lanes=2)
 
-# ---- segment timing of the G=8 step with CUDA events
-import types
-G = 8; Q = 80_000
-ix.reshard(points[0:n // G], 0, n // G)
-sq = ShardedQuery(ix, Loopback(G, 0))
-e = sq.eng
-y = torch.randn((Q, d), device=dev, dtype=torch.float32, generator=gen)
-def ev():
-    x = torch.cuda.Event(enable_timing=True); x.record(); return x
-for rep in range(3):
-    marks = [("start", ev())]
-    qs = Q // G
-    codes = sq._gather_stacked(e.codes(y[0:qs].contiguous())).reshape(-1); marks.append(("codes+gather", ev()))
-    cd, ci, nv = e.stage1_local(y, False, codes); marks.append(("stage1_local", ev()))
-    cd, ci = sq._merge(cd, ci); marks.append(("gather+merge", ev()))
-    t0 = time.perf_counter(); top_i, top_d, fl = e.finalize(cd, ci, nv); tfin = time.perf_counter() - t0; marks.append(("finalize(sync)", ev()))
-    if fl.shape[0]:
-        ids, dd = e.stage1_rows(y, False, codes, fl); e.exact_select(1, ids, dd, fl, top_i, top_d)
-    marks.append(("fallback(%d)" % fl.shape[0], ev()))
-    ids2, dd2 = e.stage2_rows(y, False, top_i, top_d); marks.append(("stage2_rows", ev()))
-    mine = torch.empty((qs, dd2.shape[1]), dtype=dd2.dtype, device=dev); sq.dist.reduce_scatter_tensor(mine, dd2)
-    loc_i = torch.empty((qs, k), dtype=torch.int32, device=dev); loc_d = torch.empty((qs, k), dtype=torch.float32, device=dev)
-    e.exact_select(2, ids2[0:qs].contiguous(), mine, None, loc_i, loc_d); marks.append(("rs+select", ev()))
-    oi = sq._gather_stacked(loc_i); od = sq._gather_stacked(loc_d); marks.append(("gather out", ev()))
+        def run_all(batches):     # two batches in flight, as bench.py --gpus N drives it
+            pend = None
+            for y in batches:
+                t = sq.submit(y)
+                if pend is not None:
+                    sq.collect(pend)
+                pend = t
+            sq.collect(pend)
+        label = "submit/collect, 2 lanes"
+    run_all(ys[:2])
     torch.cuda.synchronize()
-    if rep == 2:
+    t0 = time.perf_counter()
+    run_all(ys[2:])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 6
+    if base is None:
+        base = Q / dt
+    print("G=%d  Q=%6d  per-rank step %.3f ms (%s)  -> %.2f M q/s aggregate (compute only), scaling %.2fx"
+          % (G, Q, dt * 1e3, label, Q / dt / 1e6, (Q / dt) / base), flush=True)
+    if G > 1:   # the same step strictly serial (one lane), with CUDA events between the stages
+        sq1 = ShardedQuery(ix, Loopback(G), exchange="alltoall", lanes=1)
+        e, L = sq1.eng, sq1._lanes[0]
+        y = ys[0]
+        for rep in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ids, dd = sq1.query(y)
+            torch.cuda.synchronize()
+            serial = time.perf_counter() - t0
+        qs = (Q + G - 1) // G
+
+        def ev():
+            x = torch.cuda.Event(enable_timing=True)
+            x.record(torch.cuda.current_stream())
+            return x
+        with e.use(L.stream):
+            marks = [("start", ev())]
+            e.sh_codes(y, 0, qs, L.codes_slice); sq1._gather_cat(L.codes_all, L.codes_slice); marks.append(("codes + all-gather", ev()))
+            e.sh_stage1(y, False, L.codes_all, L.keys, L.nvalid, L.nown); marks.append(("stage1 (own rows, all queries)", ev()))
+            sq1._to_owner(L.keys_in, L.keys); marks.append(("all-to-all keys", ev()))
+            e.sh_merge_finalize(G, Q, 0, qs, L.keys_in, L.nvalid, L.top_i, L.top_d); marks.append(("merge + finalize (owner)", ev()))
+            sq1._gather_cat(L.top_all, L.top_i); marks.append(("all-gather top ids", ev()))
+            e.sh_stage2(y, False, L.top_all, L.s2, L.flagged); marks.append(("stage-2 distances (all queries)", ev()))
+            sq1._to_owner(L.s2_in, L.s2); marks.append(("all-to-all partial rows", ev()))
+            e.sh_final(G, Q, 0, qs, L.top_i, L.top_d, L.s2_in, L.out_i_slice, L.out_d_slice); marks.append(("min + network (owner)", ev()))
+            sq1._gather_cat(L.pack_all, L.pack.view(1, -1)); marks.append(("all-gather results", ev()))
+        torch.cuda.synchronize()
+        print("   serial step (1 lane) %.3f ms wall; stages by events:" % (serial * 1e3))
         for (a, ea), (b, eb) in zip(marks[:-1], marks[1:]):
-            print("  %-18s %.3f ms" % (b, ea.elapsed_time(eb)))
-        print("  total %.3f ms ; finalize host wall %.3f ms" % (marks[0][1].elapsed_time(marks[-1][1]), tfin * 1e3))
+            print("     %-34s %.3f ms" % (b, ea.elapsed_time(eb)))
+        print("     %-34s %.3f ms" % ("total", marks[0][1].elapsed_time(marks[-1][1])), flush=True)
