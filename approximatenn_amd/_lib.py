@@ -35,7 +35,8 @@ def reload_env():
 
 
 def lib_path(prec):
-    return os.path.join(CSRC, "libapproxnn_hip_%s.so" % prec)
+    # ANN_HIP_LIBDIR: load the backend from another directory (A/B builds of a kernel variant, tools/ab_build.sh)
+    return os.path.join(os.environ.get("ANN_HIP_LIBDIR", CSRC), "libapproxnn_hip_%s.so" % prec)
 
 
 def load(prec="f32"):
@@ -88,6 +89,8 @@ def load(prec="f32"):
     lib.annhip_sh_codes.argtypes = [vp, vp, sz, vp, sz, sz, u32p]
     lib.annhip_sh_stage1.argtypes = [vp, vp, sz, vp, C.c_int, u32p, vp, u32p, u32p]
     lib.annhip_sh_merge_finalize.argtypes = [vp, vp, C.c_int, sz, sz, sz, vp, u32p, u32p, vp]
+    lib.annhip_sh_exact1_begin.argtypes = [vp, vp, sz, vp, C.c_int, u32p, u32p, sz, u32p, u32p, vp]
+    lib.annhip_sh_exact1_end.argtypes = [vp, vp, sz, sz, sz, sz, u32p, u32p, vp, u32p, vp, u32p, vp]
     lib.annhip_sh_stage2.argtypes = [vp, vp, sz, vp, C.c_int, u32p, vp, u32p]
     lib.annhip_sh_final.argtypes = [vp, vp, C.c_int, sz, sz, sz, u32p, vp, vp, u32p, vp]
     lib.annhip_stage1_rows.argtypes = [vp, sz, vp, C.c_int, u32p, u32p, sz, u32p, vp]
@@ -119,7 +122,7 @@ def load(prec="f32"):
 EXPORTED = ["gpu_init", "gpu_cleanup", "register_cleanup", "query_gpu", "precomp_gpu", "annhip_precision",
             "annhip_index_create", "annhip_index_destroy", "annhip_index_info", "annhip_index_set_stream",
             "annhip_index_export", "annhip_index_reshard", "annhip_save_write", "annhip_save_read", "annhip_precomp_index", "annhip_query", "annhip_workspace_create", "annhip_workspace_destroy", "annhip_query_on", "annhip_stream_open", "annhip_stream_submit", "annhip_stream_collect", "annhip_stream_close",
-            "annhip_key_bytes", "annhip_sh_codes", "annhip_sh_stage1", "annhip_sh_merge_finalize", "annhip_sh_stage2",
+            "annhip_key_bytes", "annhip_sh_codes", "annhip_sh_stage1", "annhip_sh_merge_finalize", "annhip_sh_exact1_begin", "annhip_sh_exact1_end", "annhip_sh_stage2",
             "annhip_sh_final", "annhip_stage1_rows", "annhip_stage2_rows_list", "annhip_exact_select",
             "annhip_recall_ranks", "annhip_profile", "annhip_stats", "annhip_stage_ms",
             "annhip_cache_clear", "annhip_cache_drop", "annhip_cache_size", "annhip_reload_env",

@@ -65,7 +65,7 @@ struct EnvCfg {
   bool exact = false, slot_scan = false, point_precomp = false, all_tries = false;
   int fuse = -1;      // ANN_HIP_FUSE: -1 unset, 0 never, 1 whenever possible
   int s1_waves = 0;   // ANN_HIP_S1_WAVES: 0 unset
-  int s1_persist = -1;  // ANN_HIP_S1_PERSIST: -1 unset (auto), 0 one workgroup per query, 1 persistent multi-query workgroups
+  int segx = -1;      // ANN_HIP_SEGX: -1 unset (auto: shards of <= 30 % of the rows), 0 never, 1 whenever the shard qualifies
   size_t lds_row_max = 150 * 1024, exact_bytes = (size_t)1 << 30;
   size_t exact_rows = 0;  // ANN_HIP_EXACT_ROWS: rows of the device-driven exact workspace (0 = auto)
   int cache_mode = 0;  // ANN_HIP_CACHE: 0 sampled fingerprint (default), 1 strict (full content hash), 2 off
@@ -89,7 +89,7 @@ static void load_env() {
   c.fuse = env_int("ANN_HIP_FUSE", -1);
   c.s1_waves = env_int("ANN_HIP_S1_WAVES", 0);
   if (c.s1_waves < 1 || c.s1_waves > 4) c.s1_waves = 0;
-  c.s1_persist = env_int("ANN_HIP_S1_PERSIST", -1);
+  c.segx = env_int("ANN_HIP_SEGX", -1);
   c.lds_row_max = env_size("ANN_HIP_LDS_ROW_MAX", 150 * 1024);
   c.exact_bytes = env_size("ANN_HIP_EXACT_BYTES", (size_t)1 << 30);
   c.exact_rows = env_size("ANN_HIP_EXACT_ROWS", 0);
@@ -218,7 +218,9 @@ struct annhip_index {
   bool own_points = false;
   std::vector<u32 *> d_tabs;  // per try
   std::vector<uint2 *> d_segs;  // per try: per-bucket (first owned position, owned count, valid count)
-  bool use_seg = true;          // false when a table does not have the sorted-prefix layout (foreign save_t)
+  std::vector<uint4 *> d_segx;  // per try: 32-byte inline records (small shards only, see build_segx_kernel)
+  int use_seg = 1;              // stage-1 scan: 0 slot scan (a table without the sorted-prefix layout: foreign save_t),
+                                // 1 segment words + table rows, 2 inline records
   std::vector<TryInfo> h_tries;
   TryInfo *d_tries = NULL;
   u32 *d_graph = NULL;
@@ -299,7 +301,25 @@ static void build_segments(annhip_index *ix) {
   u32 nbad = 0;
   HIPCHECK(hipMemcpy(&nbad, bad, sizeof(u32), hipMemcpyDeviceToHost));
   HIPCHECK(hipFree(bad));
-  ix->use_seg = nbad == 0 && !env().slot_scan;
+  ix->use_seg = (nbad == 0 && !env().slot_scan) ? 1 : 0;
+  // a small shard (<= 30 % of the rows) scans through inline records: one 32-byte fetch per run instead of two fetches
+  bool small = ix->use_seg && (double)(ix->hi - ix->lo) <= 0.3 * (double)ix->n;
+  for (int t = 0; t < ix->T; t++) small = small && ix->h_tries[t].pm <= 255;
+  if (env().segx >= 0) small = small && env().segx != 0;
+  ix->d_segx.resize(ix->T, NULL);
+  for (int t = 0; t < ix->T; t++) {
+    if (small) {
+      if (!ix->d_segx[t]) ix->d_segx[t] = dev_alloc<uint4>(2 * nb);
+      build_segx_kernel<<<grid_for(nb, 256, 1u << 30), 256>>>(nb, ix->h_tries[t].pm, ix->d_tabs[t], ix->d_segs[t], ix->d_segx[t]);
+    } else if (ix->d_segx[t]) {
+      HIPCHECK(hipFree(ix->d_segx[t]));
+      ix->d_segx[t] = NULL;
+    }
+    ix->h_tries[t].segx = ix->d_segx[t];
+  }
+  HIPCHECK(hipGetLastError());
+  HIPCHECK(hipDeviceSynchronize());
+  if (small) ix->use_seg = 2;
 }
 
 static void check_limits(size_t n, size_t k, size_t d, size_t ds, int T) {
@@ -378,6 +398,8 @@ extern "C" void annhip_index_destroy(annhip_index *ix) {
   for (u32 *t : ix->d_tabs)
     if (t) HIPCHECK(hipFree(t));
   for (uint2 *sg : ix->d_segs)
+    if (sg) HIPCHECK(hipFree(sg));
+  for (uint4 *sg : ix->d_segx)
     if (sg) HIPCHECK(hipFree(sg));
   if (ix->d_tries) HIPCHECK(hipFree(ix->d_tries));
   if (ix->d_graph) HIPCHECK(hipFree(ix->d_graph));
@@ -552,7 +574,7 @@ __global__ void sum_u32_kernel(size_t count, const u32 *__restrict__ v, unsigned
 
 static void launch_stage1(annhip_index *ix, const QParams &P, size_t Q, const FT *y, int alias,
                           const u32 *codes, FT *cand_d, u32 *cand_i, u32 *nvt, u32 *nvo, hipStream_t s,
-                          const std::vector<TryInfo> &h_tries, bool use_seg, FusedTail F = FusedTail{0, 0, NULL, NULL, NULL, NULL, NULL},
+                          const std::vector<TryInfo> &h_tries, int use_seg, FusedTail F = FusedTail{0, 0, NULL, NULL, NULL, NULL, NULL},
                           Key *cand_key = NULL) {
   if (!Q) return;
   const int K1 = P.k + 1, W = stage1_waves(P.P1, (double)(P.hi - P.lo) / (double)P.n), cap = stage1_cap(W, K1);
@@ -575,20 +597,23 @@ static void launch_stage1(annhip_index *ix, const QParams &P, size_t Q, const FT
   }
   // (Chaining the stage-1 launches of overlapping batches through an event was tried and is slower, 7.9 vs 8.3 M q/s:
   // letting consecutive gathers overlap is what hides the workgroup tail of each launch.)
-#define CALL(DD)                                                                                            \
-  do {                                                                                                      \
-    if (use_seg) {                                                                                          \
-      allow_lds(stage1_select_kernel<DD, true>, smem);                                                      \
-      hipLaunchKernelGGL((stage1_select_kernel<DD, true>), dim3((unsigned)Q), dim3(64 * W), smem, s, P, (int)Q, y, \
-                         alias, codes, K1, cap, runs_used, cand_d, cand_i, nvt, nvo, F, cand_key);          \
-    } else {                                                                                                \
-      allow_lds(stage1_select_kernel<DD, false>, smem);                                                     \
-      hipLaunchKernelGGL((stage1_select_kernel<DD, false>), dim3((unsigned)Q), dim3(64 * W), smem, s, P, (int)Q, y, \
-                         alias, codes, K1, cap, runs_used, cand_d, cand_i, nvt, nvo, F, cand_key);          \
-    }                                                                                                       \
+#define CALL_V(DD, SG, FU)                                                                                   \
+  do {                                                                                                       \
+    allow_lds(stage1_select_kernel<DD, SG, FU>, smem);                                                       \
+    hipLaunchKernelGGL((stage1_select_kernel<DD, SG, FU>), dim3((unsigned)Q), dim3(64 * W), smem, s, P, (int)Q, y, \
+                       alias, codes, K1, cap, runs_used, cand_d, cand_i, nvt, nvo, F, cand_key);             \
+  } while (0)
+#define CALL(DD)                                 \
+  do {                                           \
+    if (use_seg == 2) CALL_V(DD, 2, false);                  \
+    else if (use_seg && F.enabled) CALL_V(DD, 1, true);      \
+    else if (use_seg) CALL_V(DD, 1, false);                  \
+    else if (F.enabled) CALL_V(DD, 0, true);                 \
+    else CALL_V(DD, 0, false);                               \
   } while (0)
   ANN_DISPATCH_D(P.d, CALL);
 #undef CALL
+#undef CALL_V
   HIPCHECK(hipGetLastError());
   if (prof) {
     HIPCHECK(hipEventRecord(ev.b, s));
@@ -666,11 +691,14 @@ static void launch_rows(const QParams &P, size_t Q, const FT *y, int alias, cons
 // network + rdups + network on nq rows of reference length L, `len` stored entries, row stride in_stride
 static void launch_exact_select(u32 L, u32 len, u32 in_stride, int k, size_t nq, u32 *ids, FT *dist,
                                 const u32 *qidx, u32 xbase, u32 *out_i, FT *out_d, int ostride, int ooff,
-                                hipStream_t s, const u32 *live_rows = NULL, size_t *out64 = NULL) {
+                                hipStream_t s, const u32 *live_rows = NULL, size_t *out64 = NULL, unsigned max_block = 1024) {
   if (!nq) return;
   const int lk = ann_lg(L);
   unsigned npairs = 8u << (lk > 4 ? lk - 4 : 0);
-  unsigned block = npairs >= 1024 ? 1024 : ((npairs + 63) / 64) * 64;  // one pair per thread up to the 1024 limit
+  // one pair per thread up to max_block.  1024 threads is the fastest shape on an idle GPU, but a 16-wave workgroup
+  // cannot be placed while a saturating kernel of 1-wave workgroups keeps taking every freed slot (measured: 0.1 ms
+  // alone, 1.1 ms = until the gather drained, next to the sharded stage 1): launches that run beside gathers use 256.
+  unsigned block = npairs >= max_block ? max_block : ((npairs + 63) / 64) * 64;
   if (block < 64) block = 64;
   const size_t smem = (size_t)len * (sizeof(FT) + sizeof(u32));
   const unsigned grid = live_rows ? (unsigned)std::min<size_t>(nq, 512) : (unsigned)nq;
@@ -997,11 +1025,51 @@ extern "C" void annhip_sh_merge_finalize(annhip_index *ix, void *hip_stream, int
   if (ndev < 1 || ndev > 16) die("annhip_sh_merge_finalize supports 1..16 devices");
   if (!qs) return;
   const size_t nq = q_lo < Q ? std::min(qs, Q - q_lo) : 0;
-  hipLaunchKernelGGL(merge_finalize_kernel, dim3(grid_for(qs, 128, 1u << 30)), dim3(128), 0, (hipStream_t)hip_stream, ndev,
+  const size_t smem = sizeof(Key) * 4 * (size_t)(ndev + 1) * (ix->k + 1);
+  allow_lds(merge_finalize_kernel, smem);
+  hipLaunchKernelGGL(merge_finalize_kernel, dim3((unsigned)((qs + 3) / 4)), dim3(256), smem, (hipStream_t)hip_stream, ndev,
                      (int)nq, (u32)q_lo, (u32)qs, (int)ix->k + 1, (int)ix->k, ix->L1, ix->P1,
                      reinterpret_cast<const Key *>(keys_in_dev), nvalid_dev, top_id_dev, reinterpret_cast<FT *>(top_dist_dev),
                      ix->d_rows + 2);
   HIPCHECK(hipGetLastError());
+}
+
+// Exact stage 1 of the flagged queries, device-driven (no host read-back), in two halves around one MIN all-reduce of
+// rows_dist_dev (ftype[fcap][Lc1], fixed size whatever the count):
+//   begin: ascending list of the flagged queries (flist_dev u32[2+fcap] = {listed, total, list...}) from the all-gathered
+//          top ids; ids and owned distances of the first Lc1 slots of each listed query (+inf elsewhere);
+//   end:   the reference's network on the reduced rows -> top_id_all_dev[x][0..k) (the flag disappears) and
+//          top_dist_all_dev[x][0..k); the owner's slices are patched.
+// Queries beyond fcap stay flagged: annhip_sh_stage2 lists them and the host repairs them after the step.
+extern "C" void annhip_sh_exact1_begin(annhip_index *ix, void *hip_stream, size_t Q, const ftype *y_dev, int alias,
+                                       const uint32_t *codes_dev, const uint32_t *top_id_all_dev, size_t fcap,
+                                       uint32_t *flist_dev, uint32_t *rows_id_dev, ftype *rows_dist_dev) {
+  const QParams P = make_params(ix);
+  hipStream_t s = (hipStream_t)hip_stream;
+  const unsigned nchunks = (unsigned)((Q + ANN_FLAG_CHUNK - 1) / ANN_FLAG_CHUNK);
+  u32 *chunk_cnt = reinterpret_cast<u32 *>(rows_id_dev);  // scratch until the rows kernel overwrites it (stream order)
+  if ((size_t)nchunks > fcap * (size_t)P.Lc1) die("annhip_sh_exact1_begin: batch too large for the flag scan scratch");
+  hipLaunchKernelGGL(flag_count_kernel, dim3(nchunks), dim3(ANN_FLAG_CHUNK), 0, s, (int)Q, P.k, top_id_all_dev, chunk_cnt);
+  hipLaunchKernelGGL(flag_place_kernel, dim3(nchunks), dim3(ANN_FLAG_CHUNK), 0, s, (int)Q, P.k, top_id_all_dev, chunk_cnt,
+                     (u32)fcap, flist_dev);
+  HIPCHECK(hipGetLastError());
+  launch_rows<MODE_TABLE>(P, Q, reinterpret_cast<const FT *>(y_dev), alias, codes_dev, flist_dev + 2, 0, fcap, P.Lc1, NULL,
+                          NULL, rows_id_dev, reinterpret_cast<FT *>(rows_dist_dev), ix->profile ? ix->d_rows + 8 : NULL, s,
+                          flist_dev);
+}
+
+extern "C" void annhip_sh_exact1_end(annhip_index *ix, void *hip_stream, size_t Q, size_t q_lo, size_t qs, size_t fcap,
+                                     const uint32_t *flist_dev, uint32_t *rows_id_dev, ftype *rows_dist_dev,
+                                     uint32_t *top_id_all_dev, ftype *top_dist_all_dev, uint32_t *top_id_dev,
+                                     ftype *top_dist_dev) {
+  hipStream_t s = (hipStream_t)hip_stream;
+  launch_exact_select(ix->L1, ix->Lc1, ix->Lc1, (int)ix->k, fcap, rows_id_dev, reinterpret_cast<FT *>(rows_dist_dev),
+                      flist_dev + 2, 0, top_id_all_dev, reinterpret_cast<FT *>(top_dist_all_dev), (int)ix->k, 0, s, flist_dev,
+                      NULL, 256);
+  hipLaunchKernelGGL(patch_owner_kernel, dim3(8), dim3(256), 0, s, flist_dev, (u32)q_lo, (u32)qs, (int)ix->k, top_id_all_dev,
+                     reinterpret_cast<const FT *>(top_dist_all_dev), top_id_dev, reinterpret_cast<FT *>(top_dist_dev));
+  HIPCHECK(hipGetLastError());
+  (void)Q;
 }
 
 extern "C" void annhip_sh_stage2(annhip_index *ix, void *hip_stream, size_t Q, const ftype *y_dev, int alias,
@@ -1311,10 +1379,12 @@ extern "C" annhip_index *annhip_precomp_index(size_t n, size_t k, size_t d, cons
     ix->d_segs[t] = dev_alloc<uint2>(nb);
     build_seg_kernel<<<grid_for(nb, 256, 1u << 30), 256, 0, s>>>(nb, pm, tab, (u32)n, 0u, (u32)n, ix->d_segs[t], d_bad);
     ix->h_tries[t].seg = ix->d_segs[t];
+    ix->h_tries[t].segx = NULL;
 
     // a one-try view of the index: candidate row = [ds+1][pm], codes are the points' own (no scramble)
     TryInfo one;
     one.seg = ix->d_segs[t];
+    one.segx = NULL;
     one.tab = tab, one.pm = pm, one.off = 0, one.end = (u32)((ds + 1) * pm), one.magic = magic_for(pm);
     if ((unsigned long long)one.end * pm >= (1ull << 32)) die("candidate row too long");
     HIPCHECK(hipMemcpyAsync(solo, &one, sizeof one, hipMemcpyHostToDevice, s));
@@ -1337,7 +1407,7 @@ extern "C" annhip_index *annhip_precomp_index(size_t n, size_t k, size_t d, cons
       nv = (u32 *)nvt.need(sizeof(u32) * n);
       u32 *no = (u32 *)nvo.need(sizeof(u32) * n);
       if (!launch_stage1_bucket(P, one, nb, cd, ci, nv, no, s))
-        launch_stage1(NULL, P, n, pts, 1, codes[t], cd, ci, nv, no, s, std::vector<TryInfo>(1, one), !env().slot_scan);
+        launch_stage1(NULL, P, n, pts, 1, codes[t], cd, ci, nv, no, s, std::vector<TryInfo>(1, one), env().slot_scan ? 0 : 1);
     }
     finalize_and_fallback(NULL, P, n, pts, 1, codes[t], mode, cd, ci, nv, merged_i, merged_d, (int)Wn, (int)(t * k),
                           flist, xids, xd, ix->ws.d_fcount, NULL, NULL, false, s);
@@ -1353,7 +1423,8 @@ extern "C" annhip_index *annhip_precomp_index(size_t n, size_t k, size_t d, cons
     HIPCHECK(hipMemcpy(&nbad, d_bad, sizeof(u32), hipMemcpyDeviceToHost));
     HIPCHECK(hipFree(d_bad));
     if (nbad) die("internal error: a bucket table built by precomp is not in sorted-prefix layout");
-    ix->use_seg = !env().slot_scan;
+    ix->use_seg = env().slot_scan ? 0 : 1;
+    ix->d_segx.assign(T, NULL);
   }
   cand_d.release(), cand_i.release(), nvt.release(), nvo.release(), flist.release(), xids.release(), xd.release();
 

@@ -25,6 +25,7 @@
 struct TryInfo {   // one try (= one random projection) of the index
   const u32 *tab;  // [2^ds][pm] bucket table, ids descending then padding n  (alg.c:261-266)
   const uint2 *seg;  // [2^ds] per bucket: x = first owned position | owned count << 16, y = valid count (see build_seg_kernel)
+  const uint4 *segx; // [2^ds][2] 32-byte records of a small shard: header + the first 7 owned ids inline (build_segx_kernel), or NULL
   u32 pm;          // par_maxes[t]
   u32 off;         // first slot of this try's block in the candidate row     (alg.c:484-488,449)
   u32 end;         // off + (ds+1)*pm
@@ -43,6 +44,9 @@ struct QParams {
 };
 
 #define ANN_S1_CHUNK 1024  // slots whose valid ids one wave stages in LDS at a time
+#ifndef ANN_S1_PREFETCH
+#define ANN_S1_PREFETCH 3  // row passes per wave kept in flight + 1 (gather_select)
+#endif
 
 // One 16-byte chunk of a gathered point row.  NT: query batches read each candidate row once and never again,
 // so the load is marked non-temporal and does not displace the re-used bucket tables / graph in L2 and the
@@ -210,6 +214,29 @@ __global__ void build_seg_kernel(size_t nbuckets, u32 pm, const u32 *__restrict_
   seg[b] = make_uint2(zs | (co << 16), ca);
 }
 
+// A device that owns a small part of the rows (1/4, 1/8 ...) finds about one owned id per bucket: reading the segment
+// word and then the id costs two dependent random fetches per (try, neighbour) run, and the replicated scan becomes
+// ~20 % of the stage-1 time at 8 shards.  For such shards every bucket gets ONE 32-byte record:
+//   word 0 = first owned position | owned count << 8 | valid count << 16   (par_maxes <= 255 checked on the host)
+//   words 1..7 = the first 7 owned ids (descending, as in the table row)
+// so a run costs one 32-byte fetch; buckets with more than 7 owned ids (rare on a small shard) read the rest from the
+// table row.  Built from the segment words, which have verified the layout.
+#define ANN_SEGX_INLINE 7
+__global__ void build_segx_kernel(size_t nbuckets, u32 pm, const u32 *__restrict__ tab, const uint2 *__restrict__ seg,
+                                  uint4 *__restrict__ segx) {
+  const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbuckets) return;
+  const uint2 sg = seg[b];
+  const u32 zs = sg.x & 0xFFFFu, co = sg.x >> 16, ca = sg.y;
+  u32 w[8];
+  w[0] = zs | (co << 8) | (ca << 16);
+  const u32 *row = tab + b * pm + zs;
+#pragma unroll
+  for (int j = 0; j < ANN_SEGX_INLINE; j++) w[1 + j] = (u32)j < co ? row[j] : ANN_ID_NONE;
+  segx[2 * b] = make_uint4(w[0], w[1], w[2], w[3]);
+  segx[2 * b + 1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
 __device__ __forceinline__ u32 wave_incl_scan(u32 v) {
 #pragma unroll
   for (int o = 1; o < ANN_WAVE; o <<= 1) {
@@ -243,37 +270,49 @@ __device__ __forceinline__ void gather_select(const QParams &P, const u32 *list,
                                               const FT *yq, FT *scratch, SelState &S) {
   const int lane = lane_id();
   if constexpr (D > 0) {
+    // PF row buffers per lane form a ring: while pass i is reduced, the loads of passes i+1 .. i+PF-1 are in flight
+    // (each pass = RPW rows = 64 lanes x C x 16 B).  The loop is unrolled by PF so that every buffer has a fixed
+    // register home; a buffer is re-loaded right after it has been reduced.
     typedef RowLay<D> L;
+    constexpr int PF = ANN_S1_PREFETCH;
     const int p = lane % L::LPR, g = lane / L::LPR;
-    VT bn[L::C];
-    u32 idn = 0;
-    if (cnt > 0) {
-      idn = list[g < cnt ? g : 0];
-      const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(idn - P.lo) * D) + p;
+    VT buf[PF][L::C];
+    u32 idb[PF];
 #pragma unroll
-      for (int c = 0; c < L::C; c++) bn[c] = load_row_chunk<true>(rp + c * L::LPR);
-    }
-    for (int base = 0; base < cnt; base += L::RPW) {
-      VT b[L::C];
+    for (int s = 0; s < PF; s++) {
+      const int first = s * L::RPW;
+      idb[s] = 0;
+      if (first < cnt) {
+        idb[s] = list[first + g < cnt ? first + g : first];
+        const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(idb[s] - P.lo) * D) + p;
 #pragma unroll
-      for (int c = 0; c < L::C; c++) b[c] = bn[c];
-      const u32 id = idn;
-      const bool act = base + g < cnt && !(alias && id == x);
-      const int nb = base + L::RPW;
-      if (nb < cnt) {
-        idn = list[nb + g < cnt ? nb + g : nb];
-        const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(idn - P.lo) * D) + p;
-#pragma unroll
-        for (int c = 0; c < L::C; c++) bn[c] = load_row_chunk<true>(rp + c * L::LPR);
+        for (int c = 0; c < L::C; c++) buf[s][c] = load_row_chunk<true>(rp + c * L::LPR);
       }
-      const FT dist = row_reduce<D, ROW_SQDIFF>(a, b);
-      const Key key = key_make(dist, id);
-      const bool pass = act && p == 0 && key_less(key, S.tau);
-      const u64 mm = __ballot(pass);
-      if (mm) {
-        if (pass) S.kbuf[S.kcnt + mask_rank(mm)] = key;
-        S.kcnt += __popcll(mm);
-        if (S.kcnt + L::RPW > S.cap) sel_shrink(S);
+    }
+    for (int base = 0; base < cnt; base += PF * L::RPW) {
+#pragma unroll
+      for (int s = 0; s < PF; s++) {
+        const int cur = base + s * L::RPW;
+        if (cur < cnt) {  // wave-uniform
+          const u32 id = idb[s];
+          const bool act = cur + g < cnt && !(alias && id == x);
+          const FT dist = row_reduce<D, ROW_SQDIFF>(a, buf[s]);
+          const int nb = cur + PF * L::RPW;
+          if (nb < cnt) {
+            idb[s] = list[nb + g < cnt ? nb + g : nb];
+            const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(idb[s] - P.lo) * D) + p;
+#pragma unroll
+            for (int c = 0; c < L::C; c++) buf[s][c] = load_row_chunk<true>(rp + c * L::LPR);
+          }
+          const Key key = key_make(dist, id);
+          const bool pass = act && p == 0 && key_less(key, S.tau);
+          const u64 mm = __ballot(pass);
+          if (mm) {
+            if (pass) S.kbuf[S.kcnt + mask_rank(mm)] = key;
+            S.kcnt += __popcll(mm);
+            if (S.kcnt + L::RPW > S.cap) sel_shrink(S);
+          }
+        }
       }
     }
   } else if constexpr (D < 0) {
@@ -351,7 +390,7 @@ struct FusedTail {
   unsigned long long *exact_total;
 };
 
-template <int D, bool SEG>
+template <int D, int SEG, bool FUSED>  // SEG: 0 = slot scan, 1 = segment words + table rows, 2 = inline 32-byte records
 __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, const FT *__restrict__ y,
                                                             int alias, const u32 *__restrict__ codes,
                                                             int K1, int cap, u32 runs_used,
@@ -375,7 +414,7 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
   u32 *qcode = reinterpret_cast<u32 *>(sp);              sp += sizeof(u32) * (size_t)P.T;
   int *mcnt = reinterpret_cast<int *>(sp);               sp += sizeof(int) * (size_t)W;
   u32 *cnts = reinterpret_cast<u32 *>(sp);               sp += sizeof(u32) * 4;  // [0] valid [1] gathered [2] tail list [3] rejected
-  const size_t tl = F.enabled ? F.len2 : 0;
+  const size_t tl = FUSED ? F.len2 : 0;
   u32 *t_ids = reinterpret_cast<u32 *>(sp);              sp += sizeof(u32) * tl;
   u32 *t_slot = reinterpret_cast<u32 *>(sp);             sp += sizeof(u32) * tl;
   u32 *t_gid = reinterpret_cast<u32 *>(sp);              sp += sizeof(u32) * tl;
@@ -417,7 +456,64 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
   }
 
   int cnt = 0;
-  if constexpr (SEG) {
+  if constexpr (SEG == 2) {
+    const u32 ds1 = (u32)P.ds + 1u;
+    const u32 per = (runs_used + W - 1) / W;  // runs of this wave: [r0, r1)
+    const u32 r0 = min(runs_used, (u32)w * per), r1 = min(runs_used, r0 + per);
+    for (u32 rb = r0; rb < r1; rb += ANN_WAVE) {
+      const u32 r = rb + lane;
+      u32 c = 0, va = 0;
+      uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
+      const u32 *src = NULL;
+      if (r < r1) {
+        const u32 i = r / ds1, yy = r - i * ds1;
+        const TryInfo tr = tries[i];
+        const u32 b = qcode[i] ^ (yy ? 1u << (yy - 1) : 0u);  // compute_which, compute.cl:243-245
+        const uint4 *rec = tr.segx + (size_t)b * 2;
+        v0 = rec[0], v1 = rec[1];
+        const u32 zs = v0.x & 0xFFu, co = (v0.x >> 8) & 0xFFu, ca = (v0.x >> 16) & 0xFFu;
+        const u32 zlim = min(tr.pm, P.P1 - (tr.off + yy * tr.pm));  // slots of this run below P1 (Q1)
+        va = min(ca, zlim);
+        const u32 ze = min(zs + co, zlim);
+        c = ze > zs ? ze - zs : 0u;
+        src = tr.tab + (size_t)b * tr.pm + zs;
+      }
+      vtot += va;
+      const u32 incl = wave_incl_scan(c), base = incl - c;
+      const u32 total = (u32)__builtin_amdgcn_readfirstlane((int)__shfl(incl, ANN_WAVE - 1));
+      // lanes [lo, lo + nfit) are appended per round: as many runs as still fit the list (normally all 64 at once)
+      for (u32 lo = 0; lo < ANN_WAVE;) {
+        const u32 base_lo = (u32)__builtin_amdgcn_readfirstlane((int)__shfl(base, (int)lo));
+        const u32 room = (u32)ANN_S1_CHUNK - (u32)cnt;
+        const bool fits = (u32)lane >= lo && incl - base_lo <= room;  // prefix sums are monotone: `fits` is a lane prefix
+        const u32 nfit = (u32)__popcll(__ballot(fits));
+        if (fits && c) {
+          u32 *dst = list + cnt + (base - base_lo);
+          if (c > 0) dst[0] = v0.y;
+          if (c > 1) dst[1] = v0.z;
+          if (c > 2) dst[2] = v0.w;
+          if (c > 3) dst[3] = v1.x;
+          if (c > 4) dst[4] = v1.y;
+          if (c > 5) dst[5] = v1.z;
+          if (c > 6) dst[6] = v1.w;
+          for (u32 j = ANN_SEGX_INLINE; j < c; j++) dst[j] = src[j];  // rare on a small shard
+        }
+        const u32 end = lo + nfit;
+        const u32 upto = end < ANN_WAVE ? (u32)__builtin_amdgcn_readfirstlane((int)__shfl(base, (int)(end < ANN_WAVE ? end : 0))) : total;
+        cnt += (int)(upto - base_lo);
+        lo = end;
+        if (lo < ANN_WAVE) {  // the next run does not fit any more: drain the list (a run is at most pm <= 255 ids)
+          wave_lds_sync();
+          vown += cnt;
+          gather_select<D>(P, list, cnt, alias, x, a, yq, scratch, S);
+          cnt = 0;
+        }
+      }
+      wave_lds_sync();
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) vtot += __shfl_xor(vtot, m);
+  } else if constexpr (SEG == 1) {
     const u32 ds1 = (u32)P.ds + 1u;
     const u32 per = (runs_used + W - 1) / W;  // runs of this wave: [r0, r1)
     const u32 r0 = min(runs_used, (u32)w * per), r1 = min(runs_used, r0 + per);
@@ -513,7 +609,7 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
     }
     wave_lds_sync();
     const int m = wave_select_smallest(S.kbuf, total, K1, S.kout);
-    if (!F.enabled) {
+    if constexpr (!FUSED) {
       if (cand_key) {  // sharded hosts: one packed (dist,id) key per candidate, the unit their exchange moves
         for (int i = lane; i < K1; i += ANN_WAVE) cand_key[(size_t)x * K1 + i] = i < m ? S.kout[i] : key_make(ft_inf(), ANN_ID_NONE);
       } else {
@@ -544,7 +640,7 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
       }
     }
   }
-  if (!F.enabled) return;
+  if constexpr (FUSED) {
   __syncthreads();
   if (cnts[3]) {  // exact path later; only the statistics are written here
     if (threadIdx.x == 0) nv_own[x] = cnts[1];
@@ -618,6 +714,7 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
     }
     if (threadIdx.x == 0) nv_own[x] = cnts[1] + (u32)cnt2;  // rows gathered for this query, both stages
   }
+  }  // FUSED
 }
 
 // ---------------------------------------------------------------------------------- stage1_bucket
@@ -984,46 +1081,101 @@ __global__ __launch_bounds__(1024) void exact_select_kernel(u32 L, u32 len, u32 
 // devices): in[g][xl][K1], xl = query - qbase.  One thread per query merges them to the K1 globally smallest and
 // applies finalize1's proof (see finalize1_kernel).  Accepted: top_id/top_dist[xl][0..k).  Rejected:
 // top_id[xl][0] = ANN_ID_FLAG -- every device sees the flag after the all-gather of top_id and joins the exact path.
-__global__ void merge_finalize_kernel(int G, int nq, u32 qbase, u32 qs, int K1, int k, u32 L1, u32 P1,
-                                      const Key *__restrict__ in, const u32 *__restrict__ nv_tot,
-                                      u32 *__restrict__ top_id, FT *__restrict__ top_dist,
-                                      unsigned long long *__restrict__ exact_total) {
-  const int xl = blockIdx.x * blockDim.x + threadIdx.x;
-  if (xl >= (int)qs) return;
+__global__ __launch_bounds__(256) void merge_finalize_kernel(int G, int nq, u32 qbase, u32 qs, int K1, int k, u32 L1, u32 P1,
+                                                             const Key *__restrict__ in, const u32 *__restrict__ nv_tot,
+                                                             u32 *__restrict__ top_id, FT *__restrict__ top_dist,
+                                                             unsigned long long *__restrict__ exact_total) {
+  // one wave per query: all G*K1 keys are fetched at once into LDS (no dependent loads), then the K1 smallest are
+  // selected by the same wave-level selection stage 1 uses
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = lane_id(), w = threadIdx.x >> 6, W = blockDim.x >> 6;
+  const u32 xl = blockIdx.x * W + w;
+  if (xl >= qs) return;  // whole wave
   u32 *ti = top_id + (size_t)xl * k;
   FT *td = top_dist + (size_t)xl * k;
-  if (xl >= nq) {  // padding slot of the last slice: defined content for the collectives, never read as a query
-    for (int t = 0; t < k; t++) ti[t] = ANN_ID_NONE, td[t] = ft_inf();
+  if (xl >= (u32)nq) {  // padding slot of the last slice: defined content for the collectives, never read as a query
+    for (int t = lane; t < k; t += ANN_WAVE) ti[t] = ANN_ID_NONE, td[t] = ft_inf();
     return;
   }
-  int head[16];  // G <= 16
-  for (int g = 0; g < G; g++) head[g] = 0;
-  bool flag = (u32)k > P1 || K1 != k + 1;
-  int m = 0;
-  UB prev_bits = 0;
-  for (int t = 0; t < K1; t++) {
-    int best = -1;
-    Key bk = key_max();
-    for (int g = 0; g < G; g++) {
-      if (head[g] >= K1) continue;
-      const Key c = in[((size_t)g * qs + xl) * K1 + head[g]];
-      if (key_id(c) == ANN_ID_NONE) continue;  // padding: this list is exhausted
-      if (best < 0 || key_less(c, bk)) best = g, bk = c;
-    }
-    if (best < 0) break;
-    head[best]++;
-    const UB bits = ft_bits(key_dist(bk));
-    if (m > 0 && bits == prev_bits) flag = true;  // two different ids at one distance: the network decides (Q17)
-    prev_bits = bits;
-    if (t < k) ti[t] = key_id(bk), td[t] = key_dist(bk);
-    if (t == k - 1 && !(key_dist(bk) < ft_inf())) flag = true;
-    m++;
+  Key *buf = reinterpret_cast<Key *>(smem) + (size_t)w * (G + 1) * K1, *out = buf + (size_t)G * K1;
+  const int tot = G * K1;
+  for (int e = lane; e < tot; e += ANN_WAVE) {
+    const int g = e / K1, t = e - g * K1;
+    buf[e] = in[((size_t)g * qs + xl) * K1 + t];  // padding keys (+inf, NONE) sort last and are dropped below
   }
-  if (m < k) flag = true;
-  if (L1 > P1 && nv_tot[qbase + xl] >= P1) flag = true;
-  if (flag) {
-    ti[0] = ANN_ID_FLAG;
-    if (exact_total) atomicAdd(exact_total, 1ull);
+  wave_lds_sync();
+  int m = wave_select_smallest(buf, tot, K1, out);
+  while (m > 0 && key_id(out[m - 1]) == ANN_ID_NONE) m--;  // wave-uniform (LDS reads of the same address)
+  bool bad = (u32)k > P1 || K1 != k + 1 || m < k;
+  for (int t = lane; t + 1 < m; t += ANN_WAVE)
+    if (ft_bits(key_dist(out[t])) == ft_bits(key_dist(out[t + 1]))) bad = true;  // two ids at one distance (Q17)
+  if (m >= k && !(key_dist(out[k - 1]) < ft_inf())) bad = true;
+  if (L1 > P1 && nv_tot[qbase + xl] >= P1) bad = true;
+  const bool flag = __ballot(bad) != 0;
+  for (int t = lane; t < k; t += ANN_WAVE) {
+    ti[t] = (flag && t == 0) ? ANN_ID_FLAG : (t < m ? key_id(out[t]) : ANN_ID_NONE);
+    td[t] = t < m ? key_dist(out[t]) : ft_inf();
+  }
+  if (flag && lane == 0 && exact_total) atomicAdd(exact_total, 1ull);
+}
+
+// Flagged queries in ascending order (every device derives the identical list from the all-gathered top ids):
+// flist = {n_listed = min(total, cap), total, list[cap]}.  Two passes over chunks of ANN_FLAG_CHUNK queries: per-chunk counts,
+// then every chunk places its flagged queries behind the chunks before it (ordered ballot compaction).
+#define ANN_FLAG_CHUNK 256  // small workgroups: these run beside the gather of another batch
+__global__ __launch_bounds__(ANN_FLAG_CHUNK) void flag_count_kernel(int Q, int k, const u32 *__restrict__ top_all,
+                                                                   u32 *__restrict__ chunk_cnt) {
+  __shared__ u32 total;
+  if (threadIdx.x == 0) total = 0;
+  __syncthreads();
+  const int x = blockIdx.x * ANN_FLAG_CHUNK + threadIdx.x;
+  const bool f = x < Q && top_all[(size_t)x * k] == ANN_ID_FLAG;
+  const u64 m = __ballot(f);
+  if (lane_id() == 0 && m) atomicAdd(&total, (u32)__popcll(m));
+  __syncthreads();
+  if (threadIdx.x == 0) chunk_cnt[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(ANN_FLAG_CHUNK) void flag_place_kernel(int Q, int k, const u32 *__restrict__ top_all,
+                                                                   const u32 *__restrict__ chunk_cnt, u32 cap,
+                                                                   u32 *__restrict__ flist) {
+  __shared__ u32 wsum[ANN_FLAG_CHUNK / ANN_WAVE];
+  __shared__ u32 before_s, all_s;
+  const int lane = lane_id(), w = threadIdx.x >> 6;
+  if (threadIdx.x == 0) before_s = 0, all_s = 0;
+  __syncthreads();
+  u32 mine = 0, every = 0;
+  for (u32 c = threadIdx.x; c < gridDim.x; c += blockDim.x) {
+    const u32 v = chunk_cnt[c];
+    every += v;
+    if (c < blockIdx.x) mine += v;
+  }
+#pragma unroll
+  for (int s_ = 32; s_ >= 1; s_ >>= 1) mine += __shfl_xor(mine, s_), every += __shfl_xor(every, s_);
+  if (lane == 0 && every) atomicAdd(&before_s, mine), atomicAdd(&all_s, every);
+  const int x = blockIdx.x * ANN_FLAG_CHUNK + threadIdx.x;
+  const bool f = x < Q && top_all[(size_t)x * k] == ANN_ID_FLAG;
+  const u64 m = __ballot(f);
+  if (lane == 0) wsum[w] = (u32)__popcll(m);
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0) flist[0] = min(all_s, cap), flist[1] = all_s;
+  if (f) {
+    u32 pos = before_s + mask_rank(m);
+    for (int ww = 0; ww < w; ww++) pos += wsum[ww];
+    if (pos < cap) flist[2 + pos] = (u32)x;
+  }
+}
+
+// After the exact path rewrote the flagged rows of top_all / top_d_all (rows indexed by query): the owner copies
+// its own queries' rows into its slices (top_id / top_dist [qs][k]) for the final step.
+__global__ void patch_owner_kernel(const u32 *__restrict__ flist, u32 qbase, u32 qs, int k, const u32 *__restrict__ top_all,
+                                   const FT *__restrict__ top_d_all, u32 *__restrict__ top_id, FT *__restrict__ top_dist) {
+  const u32 nl = flist[0];
+  for (u32 e = blockIdx.x * blockDim.x + threadIdx.x; e < nl * (u32)k; e += gridDim.x * blockDim.x) {
+    const u32 x = flist[2 + e / k], t = e % k;
+    if (x >= qbase && x < qbase + qs) {
+      top_id[(size_t)(x - qbase) * k + t] = top_all[(size_t)x * k + t];
+      top_dist[(size_t)(x - qbase) * k + t] = top_d_all[(size_t)x * k + t];
+    }
   }
 }
 

@@ -15,16 +15,25 @@ One step (5 collectives; the data path never touches the host):
      ((k+1)*8 B per query and rank; xGMI is point-to-point, so the 7 peers' slices travel on 7 different links)
   2. owner: merge the G lists + the single-GPU selection proof (annhip_sh_merge_finalize); rejected queries are
      flagged in place                                                -> all-gather of the top-k ids (4*k B/query)
+  2b. flagged queries (exact ties between different ids, fewer than k candidates: ~0.5 per 10k at cfg3, i.e. a few in
+     EVERY 80k-query step) take the exact path on the device: every rank derives the same ascending list, computes its
+     part of their full distance rows                                -> MIN all-reduce of a FIXED [fcap][Lc1] buffer
+     and runs the literal network; the flags disappear before stage 2.  No host decision is involved.
   3. every rank: distances of the neighbour-of-neighbour slots it owns (annhip_sh_stage2)
                                                                      -> all-to-all: partial rows go to the owner
   4. owner: min over the G partial rows, the reference's network on the stage-2 row (annhip_sh_final)
                                                                      -> all-gather of ids+distances (one packed buffer)
 
-Flagged queries (exact ties between different ids, fewer than k candidates: ~0.5 per 10k at cfg3) are REPAIRED after
-the step: all ranks compute their part of the full distance rows, two MIN all-reduces, the literal network, and the
-result rows are patched.  The flagged count is the only thing the host reads back, and it does so in collect(), not
-in the middle of the step: with submit()/collect() two batches are in flight on two HIP streams, so batch i+1's
-gather runs underneath batch i's exchanges and the host's read-back.
+More than fcap (default 32) flagged queries in one step -- duplicate-heavy data, or k beyond the sorted prefix -- are
+REPAIRED after the step: all ranks compute their part of the remaining rows, two MIN all-reduces, the literal network,
+and the result rows are patched.  The count of those is the only thing the host reads back, and it does so in
+collect(), not in the middle of the step.
+
+Streams: with submit()/collect() two batches are in flight.  All stage-1 gathers run back to back on ONE
+normal-priority HIP stream; everything else of a batch (hash, merges, stage 2, networks, the collectives' glue) runs on
+the batch's own HIGH-priority stream, so the small latency-bound kernels and the exchanges of batch i slip in
+underneath the HBM-bound gather of batch i+1 instead of queueing behind it (two gathers running concurrently only
+slow each other down -- measured).
 
 If the backend cannot do all_to_all_single the same steps run with an all-gather + local slice instead
 (exchange="allgather": G times the traffic, identical results); the choice is agreed on by all ranks at start-up.
@@ -34,6 +43,7 @@ Every rank ends with the same ids/distances, bit-identical to the single-GPU / r
 `engine` is anything with the HipEngine methods below (tests drive the same orchestration with a CPU engine built on
 the oracle under gloo); `dist` is torch.distributed (or a stand-in) or None for a single process.
 """
+import contextlib
 import os
 
 import torch
@@ -57,14 +67,27 @@ class HipEngine:
         self.device = None
         self._stream = None  # raw hipStream_t of the lane being enqueued (None = the default stream)
 
-    # -- lanes: one HIP stream per in-flight batch
-    def new_stream(self, device):
-        return torch.cuda.Stream(device=device)
+    # -- streams: one high-priority HIP stream per in-flight batch, one shared stream for the gathers
+    def new_stream(self, device, high_priority=False):
+        return torch.cuda.Stream(device=device, priority=-1 if high_priority else 0)
 
+    @contextlib.contextmanager
     def use(self, stream):
+        """Launch on `stream` (None = the default stream): the C-ABI calls and torch ops alike.  Nestable."""
+        prev = self._stream
         self._stream = stream.cuda_stream if stream is not None else None
         self.lib.annhip_index_set_stream(self.h, self._stream)
-        return torch.cuda.stream(stream)
+        try:
+            with torch.cuda.stream(stream):
+                yield
+        finally:
+            self._stream = prev
+            self.lib.annhip_index_set_stream(self.h, prev)
+
+    def event(self, stream):
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        return ev
 
     def empty(self, shape, dtype, like):
         return torch.empty(shape, dtype=dtype, device=like.device)
@@ -80,6 +103,15 @@ class HipEngine:
     def sh_merge_finalize(self, G, Q, q_lo, qs, keys_in, nvalid, top_i, top_d):
         self.lib.annhip_sh_merge_finalize(self.h, self._stream, G, Q, q_lo, qs, keys_in.data_ptr(), nvalid.data_ptr(),
                                           top_i.data_ptr(), top_d.data_ptr())
+
+    def sh_exact1_begin(self, y, alias, codes, top_all, fcap, flist, rows_i, rows_d):
+        self.lib.annhip_sh_exact1_begin(self.h, self._stream, y.shape[0], y.data_ptr(), int(alias), codes.data_ptr(),
+                                        top_all.data_ptr(), fcap, flist.data_ptr(), rows_i.data_ptr(), rows_d.data_ptr())
+
+    def sh_exact1_end(self, Q, q_lo, qs, fcap, flist, rows_i, rows_d, top_all, top_d_all, top_i, top_d):
+        self.lib.annhip_sh_exact1_end(self.h, self._stream, Q, q_lo, qs, fcap, flist.data_ptr(), rows_i.data_ptr(),
+                                      rows_d.data_ptr(), top_all.data_ptr(), top_d_all.data_ptr(), top_i.data_ptr(),
+                                      top_d.data_ptr())
 
     def sh_stage2(self, y, alias, top_all, dist_out, flagged):
         self.lib.annhip_sh_stage2(self.h, self._stream, y.shape[0], y.data_ptr(), int(alias), top_all.data_ptr(),
@@ -116,9 +148,9 @@ class _Lane:
     def __init__(self, stream):
         self.stream, self.shape, self.busy, self.event = stream, None, False, None
 
-    def ensure(self, eng, y, G, qs):
+    def ensure(self, eng, y, G, qs, fcap):
         Q = y.shape[0]
-        key = (Q, G, qs, y.device, y.dtype)
+        key = (Q, G, qs, fcap, y.device, y.dtype)
         if self.shape == key:
             return
         k, T, K1w, W2 = eng.k, eng.T, (eng.k + 1) * eng.key_words, eng.Lc2 - eng.k
@@ -130,6 +162,13 @@ class _Lane:
         self.top_i, self.top_d, self.top_all = e((qs, k), i32), e((qs, k), ft), e((Qp, k), i32)
         self.s2, self.s2_in = e((Qp, W2), ft), e((Qp, W2), ft)
         self.flagged = e((Q + 1,), i32)
+        self.top_d_all = e((Qp, k), ft)
+        self.flist, self.xrows_i, self.xrows_d = e((2 + fcap,), i32), e((fcap, eng.Lc1), i32), e((fcap, eng.Lc1), ft)
+        # the step's only host read-back: {flagged left to the host, flagged in total}, copied to pinned memory by the
+        # batch's own stream so that collect() issues no GPU work on any other stream
+        self.head_dev = e((2,), i32)
+        self.head_host = torch.empty((2,), dtype=i32, pin_memory=True) if y.is_cuda else torch.empty((2,), dtype=i32)
+        self.ids64 = e((Qp, k), i64)
         es = 4 if ft == torch.float32 else 8
         self.nb_d, self.nb_i = qs * k * es, qs * k * 4
         per = (self.nb_d + self.nb_i + 15) // 16 * 16             # this rank's results: distances, then ids, padded
@@ -146,7 +185,7 @@ class ShardedQuery:
     exchange: "alltoall" (default), "allgather" (fallback: every rank receives everything and keeps its slice), or None =
     ANN_SHARD_EXCHANGE from the environment, else probe all_to_all_single at start-up and agree across ranks."""
 
-    def __init__(self, ix_or_engine, dist=None, group=None, exchange=None, lanes=2, exact_all=None):
+    def __init__(self, ix_or_engine, dist=None, group=None, exchange=None, lanes=2, exact_all=None, fcap=32):
         self.eng = ix_or_engine if hasattr(ix_or_engine, "sh_stage1") else HipEngine(ix_or_engine)
         self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size(group) > 1) else None
         self.group = group
@@ -158,6 +197,8 @@ class ShardedQuery:
         if self.eng.k > self.eng.P1:
             self.exact_all = True           # the selection cannot be proven when k exceeds the sorted prefix (Q1)
         self.exchange = self._agree_exchange(exchange or os.environ.get("ANN_SHARD_EXCHANGE"))
+        self.fcap = max(1, int(fcap))
+        self._gather_stream = None
         self._lanes = [_Lane(None) for _ in range(max(1, lanes))]
         self._next, self._tickets = 0, {}
         self.last_exact = 0
@@ -235,30 +276,45 @@ class ShardedQuery:
         if L.busy:
             raise RuntimeError("every lane is in flight: collect() the oldest ticket first")
         if L.stream is None and y.is_cuda:
-            L.stream = e.new_stream(y.device)
+            L.stream = e.new_stream(y.device, high_priority=True)
+            if self._gather_stream is None:
+                self._gather_stream = e.new_stream(y.device)
         Q = y.shape[0]
         qs = (Q + G - 1) // G
         q_lo = r * qs
         if L.stream is not None:
             L.stream.wait_stream(torch.cuda.current_stream(y.device))   # y was produced on the caller's stream
         with e.use(L.stream):
-            L.ensure(e, y, G, qs)
+            L.ensure(e, y, G, qs, self.fcap)
             e.sh_codes(y, q_lo, q_lo + qs, L.codes_slice)
             self._gather_cat(L.codes_all, L.codes_slice)
             if self.exact_all:
                 L.top_all.fill_(ID_FLAG - (1 << 32))                     # every query takes the exact path
                 L.top_i.fill_(ID_FLAG - (1 << 32))
             else:
-                e.sh_stage1(y, alias, L.codes_all, L.keys, L.nvalid, L.nown)
+                gs = self._gather_stream if L.stream is not None else None
+                if gs is not None:
+                    gs.wait_event(e.event(L.stream))
+                with e.use(gs):                                          # gathers of all batches: back to back
+                    e.sh_stage1(y, alias, L.codes_all, L.keys, L.nvalid, L.nown)
+                if gs is not None:
+                    L.stream.wait_event(e.event(gs))
                 self._to_owner(L.keys_in, L.keys)
                 e.sh_merge_finalize(G, Q, q_lo, qs, L.keys_in, L.nvalid, L.top_i, L.top_d)
                 self._gather_cat(L.top_all, L.top_i)
+            # flagged queries: exact stage 1 on the device, one fixed-size MIN all-reduce in the middle
+            e.sh_exact1_begin(y, alias, L.codes_all, L.top_all, self.fcap, L.flist, L.xrows_i, L.xrows_d)
+            self._all_min(L.xrows_d)
+            e.sh_exact1_end(Q, q_lo, qs, self.fcap, L.flist, L.xrows_i, L.xrows_d, L.top_all, L.top_d_all, L.top_i, L.top_d)
             e.sh_stage2(y, alias, L.top_all, L.s2, L.flagged)
             self._to_owner(L.s2_in, L.s2)
             e.sh_final(G, Q, q_lo, qs, L.top_i, L.top_d, L.s2_in, L.out_i_slice, L.out_d_slice)
             self._gather_cat(L.pack_all, L.pack.view(1, -1))
             L.out_d.view(G, qs * e.k).copy_(L.pack_all[:, : L.nb_d].view(e.ft))
             L.out_i.view(G, qs * e.k).copy_(L.pack_all[:, L.nb_d: L.nb_d + L.nb_i].view(torch.int32))
+            L.head_dev[0:1].copy_(L.flagged[0:1])
+            L.head_dev[1:2].copy_(L.flist[1:2])
+            L.head_host.copy_(L.head_dev, non_blocking=True)
             if L.stream is not None:
                 L.event = torch.cuda.Event()
                 L.event.record(L.stream)
@@ -274,13 +330,15 @@ class ShardedQuery:
         L = self._tickets.pop(ticket)
         if L.event is not None:
             L.event.synchronize()
-        nf = int(L.flagged[:1].cpu()[0])      # the one host read-back of the step; identical on every rank
-        self.last_exact = nf
+        nf = int(L.head_host[0])              # flagged queries the device-driven exact path had no room for; the same
+        self.last_exact = int(L.head_host[1])  # on every rank.  [1] = all flagged queries of the batch
         with e.use(L.stream):
             if nf:
                 self._repair(L, nf)
             Q = L.Q
-            ids, dd = _u32(L.out_i[:Q]), L.out_d[:Q].clone()
+            L.ids64.copy_(L.out_i)                                   # u32 bit patterns -> the ABI's 64-bit ids
+            L.ids64.bitwise_and_(0xFFFFFFFF)
+            ids, dd = L.ids64[:Q].clone(), L.out_d[:Q].clone()
             if L.stream is not None:
                 torch.cuda.current_stream(L.y.device).wait_stream(L.stream)
         L.busy, L.y = False, None
@@ -291,7 +349,7 @@ class ShardedQuery:
         all-reduce, the literal network; then their stage-2 rows the same way; the result rows are patched."""
         e, y, alias = self.eng, L.y, L.alias
         fl = torch.sort(_u32(L.flagged[1:1 + nf])).values.to(torch.int32)   # appended by atomics: sort => same order everywhere
-        top_d_all = e.empty(tuple(L.top_all.shape), e.ft, y)
+        top_d_all = L.top_d_all
         ids1, dd1 = e.stage1_rows(y, alias, L.codes_all, fl)
         self._all_min(dd1)
         e.exact_select(1, ids1, dd1, fl, L.top_all, top_d_all)

@@ -124,6 +124,18 @@ void annhip_sh_stage1(annhip_index *ix, void *hip_stream, size_t ycnt, const fty
 void annhip_sh_merge_finalize(annhip_index *ix, void *hip_stream, int ndev, size_t ycnt, size_t q_lo, size_t qs,
                               const void *keys_in_dev, const uint32_t *nvalid_dev, uint32_t *top_id_dev,
                               ftype *top_dist_dev);
+/* 2b. exact stage 1 of the flagged queries, device-driven, around ONE fixed-size MIN all-reduce of rows_dist_dev
+ *    (ftype[fcap][Lc1]):  begin = ascending list of the flagged queries, flist_dev u32[2+fcap] = {listed, total, list},
+ *    derived from top_id_all_dev (identical on every device), + ids / owned distances of their first Lc1 slots;
+ *    end = the reference's network on the reduced rows -> top_id_all_dev[x] (the flag disappears), top_dist_all_dev
+ *    ftype[>=ycnt][k], and the owner's slices.  Flagged queries beyond fcap stay flagged (step 3 lists them). */
+void annhip_sh_exact1_begin(annhip_index *ix, void *hip_stream, size_t ycnt, const ftype *y_dev, int alias,
+                            const uint32_t *codes_dev, const uint32_t *top_id_all_dev, size_t fcap,
+                            uint32_t *flist_dev, uint32_t *rows_id_dev, ftype *rows_dist_dev);
+void annhip_sh_exact1_end(annhip_index *ix, void *hip_stream, size_t ycnt, size_t q_lo, size_t qs, size_t fcap,
+                          const uint32_t *flist_dev, uint32_t *rows_id_dev, ftype *rows_dist_dev,
+                          uint32_t *top_id_all_dev, ftype *top_dist_all_dev, uint32_t *top_id_dev,
+                          ftype *top_dist_dev);
 /* 3. every device, all queries: top_id_all_dev u32[>=ycnt][k] (the all-gather of step 2) -> dist_out_dev
  *    ftype[ycnt][Lc2-k] = distances of the stage-2 slots k..Lc2-1 this device owns, +inf elsewhere (supercharge,
  *    compute.cl:252-263 + compdists, alg.c:314-326).  Flagged queries are skipped and listed:

@@ -142,6 +142,29 @@ class CpuShardEngine:
             if flag:
                 ti[xl, 0] = 0xFFFFFFFE
 
+    def sh_exact1_begin(self, y, alias, codes, top_all, fcap, flist, rows_i, rows_d):
+        Q = y.shape[0]
+        ta, fl = top_all.numpy().view(np.uint32), flist.numpy().view(np.uint32)
+        flagged = [x for x in range(Q) if ta[x, 0] == 0xFFFFFFFE]
+        fl[0], fl[1] = min(len(flagged), fcap), len(flagged)
+        fl[2:2 + fl[0]] = flagged[:fcap]
+        if fl[0]:
+            ids, dd = self.stage1_rows(y, alias, codes, torch.from_numpy(fl[2:2 + fl[0]].astype(np.int32)))
+            rows_i.numpy()[: fl[0]] = ids.numpy()
+            rows_d.numpy()[: fl[0]] = dd.numpy()
+
+    def sh_exact1_end(self, Q, q_lo, qs, fcap, flist, rows_i, rows_d, top_all, top_d_all, top_i, top_d):
+        fl = flist.numpy().view(np.uint32)
+        nl = int(fl[0])
+        if not nl:
+            return
+        qidx = torch.from_numpy(fl[2:2 + nl].astype(np.int32))
+        self.exact_select(1, rows_i[:nl], rows_d[:nl], qidx, top_all, top_d_all)
+        for x in fl[2:2 + nl]:
+            if q_lo <= x < q_lo + qs:
+                top_i.numpy()[x - q_lo] = top_all.numpy()[x]
+                top_d.numpy()[x - q_lo] = top_d_all.numpy()[x]
+
     def _stage2_id(self, ti_row, j):
         k, n = self.k, self.n
         parent, z = int(ti_row[j // k - 1]), j % k

@@ -166,3 +166,27 @@ def test_sharded_exact_everywhere(monkeypatch):
     g = load_golden("pow2_d32_f32")
     for ids, dd, nex in _run_sharded("f32", g["save"], g["points"], g["y"], 2):
         assert np.array_equal(ids, g["query_ids"]) and bits_equal(dd, g["query_dists"]) and nex == len(g["y"])
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_small_shards_with_a_heavy_bucket(prec):
+    """Shards of 1/4 and 1/8 of the rows scan through the inline 32-byte bucket records; a cluster of near-identical
+    points makes buckets with far more than the 7 owned ids a record holds, so the table-row continuation runs too."""
+    orc = O.CpuBackend(prec, "oracle")
+    O.srandom(2025)
+    orc.rand_norm_reset()
+    n, d, k, T, Q = 4000, 32, 5, 3, 96
+    pts = orc.gen_rand(n * d).reshape(n, d)
+    rng = np.random.default_rng(3)
+    heavy = rng.choice(n, size=120, replace=False)
+    pts[heavy] = pts[heavy[0]] + (1e-3 * orc.gen_rand(120 * d).reshape(120, d)).astype(pts.dtype)
+    y = orc.gen_rand(Q * d).reshape(Q, d)
+    y[:32] = pts[heavy[0]] + (1e-2 * orc.gen_rand(32 * d).reshape(32, d)).astype(pts.dtype)   # these probe the heavy bucket
+    pts, y = np.ascontiguousarray(pts), np.ascontiguousarray(y)
+    O.srandom(8)
+    _, _, o_save = orc.precomp(pts, k, T)
+    assert max(int(v) for v in o_save["par_maxes"]) > 60 and max(int(v) for v in o_save["par_maxes"]) <= 255
+    want = orc.query(o_save, pts, y)
+    for world in (4, 8):
+        for ids, dd, _ in _run_sharded(prec, o_save, pts, y, world):
+            assert np.array_equal(ids, want[0]) and bits_equal(dd, want[1]), world

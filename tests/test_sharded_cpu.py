@@ -48,12 +48,17 @@ def _worker(rank, world, port, case, mode="plain"):
             pts, y, save, want_ids, want_d, prec = g["points"], g["y"], g["save"], g["query_ids"], g["query_dists"], g["prec"]
         lo, hi = _bounds(len(pts), world, rank)
         eng = CpuShardEngine(save, pts, lo, hi, prec)
-        sq = ShardedQuery(eng, dist)
+        # ties: nearly every query is flagged; fcap = 3 leaves most of them to the host-driven repair after the step
+        sq = ShardedQuery(eng, dist, fcap=3 if case == "ties" else 32)
         ids, dd = sq.query(torch.from_numpy(np.ascontiguousarray(y)))
         assert np.array_equal(ids.numpy().astype(np.uint64), want_ids), "rank %d ids" % rank
         assert bits_equal(dd.numpy(), want_d), "rank %d dists" % rank
         if case == "ties":
-            assert sq.last_exact > 0
+            assert sq.last_exact > 3
+            sq2 = ShardedQuery(eng, dist)       # default fcap: all of them on the device-driven path
+            ids, dd = sq2.query(torch.from_numpy(np.ascontiguousarray(y)))
+            assert np.array_equal(ids.numpy().astype(np.uint64), want_ids) and bits_equal(dd.numpy(), want_d)
+            assert sq2.last_exact == sq.last_exact
     finally:
         dist.destroy_process_group()
 

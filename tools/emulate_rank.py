@@ -24,6 +24,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--points", type=int, default=10_000_000)
 ap.add_argument("--queries", type=int, default=10_000)
 ap.add_argument("--worlds", type=str, default="1,2,4,8")
+ap.add_argument("--lanes", type=int, default=3)
+ap.add_argument("--steps", type=int, default=12)
 args = ap.parse_args()
 
 
@@ -65,7 +67,7 @@ ix = A.Index.precomp(points, k, T)
 base = None
 for G in [int(g) for g in args.worlds.split(",")]:
     Q = args.queries * G
-    ys = [torch.randn((Q, d), device=dev, dtype=torch.float32, generator=gen) for _ in range(8)]
+    ys = [torch.randn((Q, d), device=dev, dtype=torch.float32, generator=gen) for _ in range(4 + args.steps)]
     if G == 1:
         def run_all(batches):
             for y in batches:
@@ -74,27 +76,39 @@ for G in [int(g) for g in args.worlds.split(",")]:
     else:
         lo, hi = 0, n // G
         ix.reshard(points[lo:hi], lo, hi)
-        sq = ShardedQuery(ix, Loopback(G), exchange="alltoall", lanes=2)
+        sq = ShardedQuery(ix, Loopback(G), exchange="alltoall", lanes=args.lanes)
 
-        def run_all(batches):     # two batches in flight, as bench.py --gpus N drives it
-            pend = None
+        host = {"submit": 0.0, "collect": 0.0, "n": 0}
+
+        def run_all(batches):     # several batches in flight, as bench.py --gpus N drives it
+            pend = []
             for y in batches:
-                t = sq.submit(y)
-                if pend is not None:
-                    sq.collect(pend)
-                pend = t
-            sq.collect(pend)
-        label = "submit/collect, 2 lanes"
-    run_all(ys[:2])
+                if len(pend) == args.lanes:
+                    t0 = time.perf_counter()
+                    sq.collect(pend.pop(0))
+                    host["collect"] += time.perf_counter() - t0
+                t0 = time.perf_counter()
+                pend.append(sq.submit(y))
+                host["submit"] += time.perf_counter() - t0
+                host["n"] += 1
+            while pend:
+                sq.collect(pend.pop(0))
+        label = "submit/collect, %d lanes" % args.lanes
+    run_all(ys[:4])
     torch.cuda.synchronize()
+    if G > 1:
+        host.update(submit=0.0, collect=0.0, n=0)
     t0 = time.perf_counter()
-    run_all(ys[2:])
+    run_all(ys[4:])
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / 6
+    dt = (time.perf_counter() - t0) / args.steps
     if base is None:
         base = Q / dt
     print("G=%d  Q=%6d  per-rank step %.3f ms (%s)  -> %.2f M q/s aggregate (compute only), scaling %.2fx"
           % (G, Q, dt * 1e3, label, Q / dt / 1e6, (Q / dt) / base), flush=True)
+    if G > 1:
+        print("   host time per step: submit %.3f ms, collect (incl. waiting for the GPU) %.3f ms"
+              % (host["submit"] / host["n"] * 1e3, host["collect"] / host["n"] * 1e3))
     if G > 1:   # the same step strictly serial (one lane), with CUDA events between the stages
         sq1 = ShardedQuery(ix, Loopback(G), exchange="alltoall", lanes=1)
         e, L = sq1.eng, sq1._lanes[0]
@@ -118,12 +132,16 @@ for G in [int(g) for g in args.worlds.split(",")]:
             sq1._to_owner(L.keys_in, L.keys); marks.append(("all-to-all keys", ev()))
             e.sh_merge_finalize(G, Q, 0, qs, L.keys_in, L.nvalid, L.top_i, L.top_d); marks.append(("merge + finalize (owner)", ev()))
             sq1._gather_cat(L.top_all, L.top_i); marks.append(("all-gather top ids", ev()))
+            e.sh_exact1_begin(y, False, L.codes_all, L.top_all, sq1.fcap, L.flist, L.xrows_i, L.xrows_d)
+            sq1._all_min(L.xrows_d)
+            e.sh_exact1_end(Q, 0, qs, sq1.fcap, L.flist, L.xrows_i, L.xrows_d, L.top_all, L.top_d_all, L.top_i, L.top_d)
+            marks.append(("exact stage 1 of the flagged", ev()))
             e.sh_stage2(y, False, L.top_all, L.s2, L.flagged); marks.append(("stage-2 distances (all queries)", ev()))
             sq1._to_owner(L.s2_in, L.s2); marks.append(("all-to-all partial rows", ev()))
             e.sh_final(G, Q, 0, qs, L.top_i, L.top_d, L.s2_in, L.out_i_slice, L.out_d_slice); marks.append(("min + network (owner)", ev()))
             sq1._gather_cat(L.pack_all, L.pack.view(1, -1)); marks.append(("all-gather results", ev()))
         torch.cuda.synchronize()
-        print("   serial step (1 lane) %.3f ms wall; stages by events:" % (serial * 1e3))
+        print("   serial step (1 lane) %.3f ms wall; %d flagged queries; stages by events:" % (serial * 1e3, int(L.flist[1].item())))
         for (a, ea), (b, eb) in zip(marks[:-1], marks[1:]):
             print("     %-34s %.3f ms" % (b, ea.elapsed_time(eb)))
         print("     %-34s %.3f ms" % ("total", marks[0][1].elapsed_time(marks[-1][1])), flush=True)
