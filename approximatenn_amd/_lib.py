@@ -86,6 +86,9 @@ def load(prec="f32"):
     lib.annhip_stream_close.argtypes = [vp]
     lib.annhip_key_bytes.restype = sz
     lib.annhip_key_bytes.argtypes = []
+    lib.annhip_stream_create_reserving.restype = vp
+    lib.annhip_stream_create_reserving.argtypes = [C.c_int]
+    lib.annhip_stream_destroy.argtypes = [vp]
     lib.annhip_sh_codes.argtypes = [vp, vp, sz, vp, sz, sz, u32p]
     lib.annhip_sh_stage1.argtypes = [vp, vp, sz, vp, C.c_int, u32p, vp, u32p, u32p]
     lib.annhip_sh_merge_finalize.argtypes = [vp, vp, C.c_int, sz, sz, sz, vp, u32p, u32p, vp]
@@ -122,7 +125,7 @@ def load(prec="f32"):
 EXPORTED = ["gpu_init", "gpu_cleanup", "register_cleanup", "query_gpu", "precomp_gpu", "annhip_precision",
             "annhip_index_create", "annhip_index_destroy", "annhip_index_info", "annhip_index_set_stream",
             "annhip_index_export", "annhip_index_reshard", "annhip_save_write", "annhip_save_read", "annhip_precomp_index", "annhip_query", "annhip_workspace_create", "annhip_workspace_destroy", "annhip_query_on", "annhip_stream_open", "annhip_stream_submit", "annhip_stream_collect", "annhip_stream_close",
-            "annhip_key_bytes", "annhip_sh_codes", "annhip_sh_stage1", "annhip_sh_merge_finalize", "annhip_sh_exact1_begin", "annhip_sh_exact1_end", "annhip_sh_stage2",
+            "annhip_key_bytes", "annhip_stream_create_reserving", "annhip_stream_destroy", "annhip_sh_codes", "annhip_sh_stage1", "annhip_sh_merge_finalize", "annhip_sh_exact1_begin", "annhip_sh_exact1_end", "annhip_sh_stage2",
             "annhip_sh_final", "annhip_stage1_rows", "annhip_stage2_rows_list", "annhip_exact_select",
             "annhip_recall_ranks", "annhip_profile", "annhip_stats", "annhip_stage_ms",
             "annhip_cache_clear", "annhip_cache_drop", "annhip_cache_size", "annhip_reload_env",

@@ -997,6 +997,30 @@ extern "C" void annhip_exact_select(annhip_index *ix, int stage, size_t nq, uint
                       out_id_dev, reinterpret_cast<FT *>(out_dist_dev), (int)ix->k, 0, ix->stream);
 }
 
+// A HIP stream whose kernels may use every compute unit except `reserve` of them (the highest-numbered ones).
+// Used for the stage-1 gathers of a sharded host: that kernel would otherwise occupy every wave slot of the GPU, and
+// the small kernels and RCCL collectives of the other in-flight batch wait for slots (a multi-wave workgroup can wait
+// until the gather has drained).  The gather is HBM-bound and does not need the last few CUs.  NULL if unsupported.
+extern "C" void *annhip_stream_create_reserving(int reserve) {
+  gpu_init();
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return NULL;
+  const int ncu = prop.multiProcessorCount;
+  if (reserve < 0 || reserve >= ncu) return NULL;
+  std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+  for (int cu = 0; cu < ncu - reserve; cu++) mask[cu / 32] |= 1u << (cu % 32);
+  hipStream_t st = NULL;
+  if (hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+    (void)hipGetLastError();
+    return NULL;
+  }
+  return st;
+}
+extern "C" void annhip_stream_destroy(void *hip_stream) {
+  if (hip_stream) (void)hipStreamDestroy((hipStream_t)hip_stream);
+}
+
 // ---- point-sharded hosts, owner protocol (approximatenn_amd/sharded.py).  Every call is
 // asynchronous on the given HIP stream and touches no index-owned scratch, so several batches can be in flight.
 extern "C" size_t annhip_key_bytes(void) { return sizeof(Key); }

@@ -68,7 +68,13 @@ class HipEngine:
         self._stream = None  # raw hipStream_t of the lane being enqueued (None = the default stream)
 
     # -- streams: one high-priority HIP stream per in-flight batch, one shared stream for the gathers
-    def new_stream(self, device, high_priority=False):
+    def new_stream(self, device, high_priority=False, reserve_cus=0):
+        """reserve_cus > 0: a stream that leaves that many compute units to the other streams (the gathers' stream)."""
+        if reserve_cus > 0:
+            with torch.cuda.device(device):
+                ptr = self.lib.annhip_stream_create_reserving(int(reserve_cus))
+            if ptr:
+                return torch.cuda.ExternalStream(ptr, device=device)
         return torch.cuda.Stream(device=device, priority=-1 if high_priority else 0)
 
     @contextlib.contextmanager
@@ -185,7 +191,8 @@ class ShardedQuery:
     exchange: "alltoall" (default), "allgather" (fallback: every rank receives everything and keeps its slice), or None =
     ANN_SHARD_EXCHANGE from the environment, else probe all_to_all_single at start-up and agree across ranks."""
 
-    def __init__(self, ix_or_engine, dist=None, group=None, exchange=None, lanes=2, exact_all=None, fcap=32):
+    def __init__(self, ix_or_engine, dist=None, group=None, exchange=None, lanes=2, exact_all=None, fcap=32,
+                 reserve_cus=None):
         self.eng = ix_or_engine if hasattr(ix_or_engine, "sh_stage1") else HipEngine(ix_or_engine)
         self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size(group) > 1) else None
         self.group = group
@@ -198,6 +205,8 @@ class ShardedQuery:
             self.exact_all = True           # the selection cannot be proven when k exceeds the sorted prefix (Q1)
         self.exchange = self._agree_exchange(exchange or os.environ.get("ANN_SHARD_EXCHANGE"))
         self.fcap = max(1, int(fcap))
+        # compute units the gathers leave to everything else (small kernels, RCCL); ANN_SHARD_RESERVE_CUS overrides
+        self.reserve_cus = int(os.environ.get("ANN_SHARD_RESERVE_CUS", 0 if reserve_cus is None else reserve_cus))
         self._gather_stream = None
         self._lanes = [_Lane(None) for _ in range(max(1, lanes))]
         self._next, self._tickets = 0, {}
@@ -278,7 +287,7 @@ class ShardedQuery:
         if L.stream is None and y.is_cuda:
             L.stream = e.new_stream(y.device, high_priority=True)
             if self._gather_stream is None:
-                self._gather_stream = e.new_stream(y.device)
+                self._gather_stream = e.new_stream(y.device, reserve_cus=self.reserve_cus)
         Q = y.shape[0]
         qs = (Q + G - 1) // G
         q_lo = r * qs

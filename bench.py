@@ -100,8 +100,16 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     if world > 1:
-        backend = "gloo" if shared_gpu else "nccl"  # "nccl" is RCCL on ROCm
-        dist.init_process_group(backend=backend)
+        if shared_gpu:
+            dist.init_process_group(backend="gloo")
+        else:  # "nccl" is RCCL on ROCm.  Its kernels run beside the other batch's gather, which would otherwise take
+            # every freed wave slot first: give the communicator's stream the high priority the batches' streams have.
+            opts = None
+            try:
+                opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            except Exception:  # noqa: BLE001
+                pass
+            dist.init_process_group(backend="nccl", pg_options=opts, device_id=device)
 
     n, d, k, T = args.n, args.d, args.k, args.tries
     tdt = torch.float32 if args.dtype == "f32" else torch.float64

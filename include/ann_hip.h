@@ -107,6 +107,11 @@ void annhip_stream_close(annhip_stream *st);
  * (a hipStream_t) and uses caller-provided buffers only, so several batches can be in flight on several streams.
  * "keys" are packed (squared distance bits, id) pairs of annhip_key_bytes() bytes each (8 for float, 16 for double). */
 size_t annhip_key_bytes(void);
+/* A HIP stream (hipStream_t) that may use every compute unit but `reserve` of them -- for the stage-1 gathers, so that
+ * the small kernels and the RCCL collectives of the other in-flight batch always find free wave slots.  NULL if the
+ * runtime refuses; release with annhip_stream_destroy. */
+void *annhip_stream_create_reserving(int reserve);
+void annhip_stream_destroy(void *hip_stream);
 /* 0. hash codes of queries [q_lo,q_hi) of the batch: codes_slice_dev u32[(q-q_lo)*tries+t] (alg.c:462-492).  The
  *    all-gather of the slices is the [q*tries+t] array of the whole batch that stage 1 reads as [t*ycnt+q] (Q2).
  *    Only the codes stage 1 can read are computed (Q1). */

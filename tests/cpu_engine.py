@@ -72,7 +72,7 @@ class CpuShardEngine:
     # ---- HipEngine interface: lanes and buffers
     key_words = property(lambda self: 1 if self.prec == "f32" else 2)
 
-    def new_stream(self, device):
+    def new_stream(self, device, high_priority=False, reserve_cus=0):
         return None
 
     def use(self, stream):
