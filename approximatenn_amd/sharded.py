@@ -194,7 +194,9 @@ class ShardedQuery:
     def __init__(self, ix_or_engine, dist=None, group=None, exchange=None, lanes=2, exact_all=None, fcap=32,
                  reserve_cus=None):
         self.eng = ix_or_engine if hasattr(ix_or_engine, "sh_stage1") else HipEngine(ix_or_engine)
-        self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size(group) > 1) else None
+        # ANN_SHARD_FORCE_DIST=1: keep the collectives even with ONE rank (rehearses the RCCL calls on a single-GPU box)
+        self.dist = dist if (dist is not None and dist.is_initialized() and
+                             (dist.get_world_size(group) > 1 or os.environ.get("ANN_SHARD_FORCE_DIST") == "1")) else None
         self.group = group
         self.world = self.dist.get_world_size(group) if self.dist else 1
         self.rank = self.dist.get_rank(group) if self.dist else 0

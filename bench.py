@@ -95,11 +95,13 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
         args.gpus = world
     shared_gpu = os.environ.get("ANN_BENCH_SHARED_GPU") == "1"  # rehearsal: all ranks on GPU 0, gloo collectives
+    rehearse_rccl = os.environ.get("ANN_SHARD_FORCE_DIST") == "1" and "RANK" in os.environ  # 1 rank, real RCCL calls
     dev_index = 0 if shared_gpu else local_rank
     os.environ["ANN_HIP_DEVICE"] = str(dev_index)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    sharded = world > 1 or rehearse_rccl
+    if sharded:
         if shared_gpu:
             dist.init_process_group(backend="gloo")
         else:  # "nccl" is RCCL on ROCm.  Its kernels run beside the other batch's gather, which would otherwise take
@@ -142,7 +144,7 @@ def main():
         batches = [torch.randn((Q, d), device=device, dtype=tdt, generator=gen) for _ in range(nbatches)]
 
     runner = None
-    if world > 1:
+    if sharded:
         from approximatenn_amd.sharded import ShardedQuery
         lo, hi = (n * rank) // world, (n * (rank + 1)) // world
         shard = points[lo:hi].clone()
@@ -175,7 +177,7 @@ def main():
                     ix.query(y, out_ids=out_ids[j], out_dists=out_d[j], ws=lanes[j][0], stream=lanes[j][1])
 
     def barrier():
-        if world > 1:
+        if sharded:
             dist.barrier()
 
     def timed(ys):
@@ -188,7 +190,7 @@ def main():
         torch.cuda.synchronize()
         barrier()
         el = time.perf_counter() - t0
-        if world > 1:
+        if sharded:
             tt = torch.tensor([el], dtype=torch.float64, device="cpu" if shared_gpu else device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
@@ -200,7 +202,7 @@ def main():
     ix.profile(os.environ.get("ANN_BENCH_NO_EVENTS") != "1")
     elapsed, submit_s = timed(batches[args.warmup:])
     st = ix.stats()
-    stage_ms = ix.stage_ms() if world == 1 else None
+    stage_ms = ix.stage_ms() if not sharded else None
     ix.profile(False)
 
     # ---- roofline of the dominant kernel (stage1_select): algorithmic bytes / HIP-event time
@@ -214,7 +216,7 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
                 "rows_gathered_per_query": round(v1, 1)}
-    if world > 1:
+    if sharded:
         roofline["note"] = "rank 0's kernel; with two batches in flight it overlaps the other batch's small kernels"
 
     # PMC counters cannot be read in-process: for the default workload the figure is the committed rocprofv3 --pmc
@@ -222,7 +224,7 @@ def main():
     tag, wl_short, wl_long = describe(n, d, k, T, Q, args.dtype)
     try:
         tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        if world == 1 and (n, d, k, T, Q, args.dtype) == (10_000_000, 128, 10, 10, 10_000, "f32"):
+        if not sharded and (n, d, k, T, Q, args.dtype) == (10_000_000, 128, 10, 10, 10_000, "f32"):
             roofline["traffic"] = tr["traffic_bytes_per_launch"]
             roofline["traffic_source"] = "static, from the committed rocprofv3 --pmc passes: " + tr["source"]
     except (OSError, ValueError, KeyError):
@@ -239,7 +241,7 @@ def main():
                                           "(randNorm.c:9-21), srandom(%d)" % args.seed) if args.data == "randnorm"
                        else "iid N(0,1), torch.randn on the device, seed %d" % args.seed,
                        "points_sharding": "rows/%d" % world,
-                       "streams": (max(1, args.streams) if world == 1 else 2), "d_short": ix.d_short, "L1": ix.L1, "P1": ix.P1,
+                       "streams": (max(1, args.streams) if not sharded else 2), "d_short": ix.d_short, "L1": ix.L1, "P1": ix.P1,
                        "L2": ix.L2, "P2": ix.P2, "sum_par_maxes": ix.sum_pm, "datagen_s": round(datagen_s, 2),
                        "precomp_s": round(precomp_s, 2),
                        "exact_path_queries_per_step": round(st["exact_queries"] / args.steps, 2),
@@ -252,7 +254,7 @@ def main():
         line["config"]["queries_per_step_total"] = Q
 
     # ---- N > 1 extra: strong scaling -- the batch FIXED at --queries in total (10k), sharded the same way
-    if world > 1 and not args.no_strong_extra:
+    if sharded and not args.no_strong_extra:
         Qs = args.q
         ys = [b[:Qs].contiguous() for b in batches]
         run_steps(ys[:args.warmup])
@@ -264,7 +266,7 @@ def main():
 
     # ---- extra: the same K steps with consecutive batches overlapped on two streams (annhip_query_on); reported
     #      beside `value`, never instead of it: per-launch kernel times are not meaningful while gathers overlap
-    if world == 1 and rank == 0 and max(1, args.streams) == 1 and not args.no_overlap_extra:
+    if not sharded and rank == 0 and max(1, args.streams) == 1 and not args.no_overlap_extra:
         lanes2 = [(ix.workspace(), torch.cuda.Stream(device=device)) for _ in range(2)]
         o_ids = [torch.empty((Q, k), dtype=torch.int64, device=device) for _ in range(2)]
         o_d = [torch.empty((Q, k), dtype=tdt, device=device) for _ in range(2)]
@@ -279,14 +281,14 @@ def main():
                            "ms_per_step": round(dt / args.steps * 1e3, 4),
                            "note": "consecutive batches on 2 HIP streams/workspaces; same work, same results"}
     # ---- quality of the answers (not part of the metric): exact-rank recall of a 512-query sample, by GPU brute force
-    if world == 1 and rank == 0:
+    if not sharded and rank == 0:
         qs = min(512, Q)
         g_ids, _, _ = ix.query(batches[0][:qs].contiguous())
         rk = A.recall_ranks(points, batches[0][:qs].contiguous(), g_ids)
         line["config"]["recall_sample"] = {kk: round(v, 4) for kk, v in A.recall_summary(rk, k).items()}
         line["config"]["recall_sample"]["queries"] = qs
     # ---- host-pointer API + CPU baseline share one exported save_t and one host copy of the points
-    if world == 1 and rank == 0 and not (args.no_cpu_baseline and args.no_host_api):
+    if not sharded and rank == 0 and not (args.no_cpu_baseline and args.no_host_api):
         if host_pts is None:
             host_pts = points.cpu().numpy()
         save = ix.export()
@@ -298,7 +300,7 @@ def main():
     if rank == 0:
         print(json.dumps(line), flush=True)
     ix.close()
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 

@@ -80,3 +80,17 @@ def test_bench_multi_rank_fallback_exchange():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.strip().startswith("{")][0])
     assert d["n_gpus"] == 2 and d["config"]["exchange"] == "allgather" and "strong" not in d
+
+
+def test_bench_single_rank_over_rccl():
+    """ANN_SHARD_FORCE_DIST=1 with ONE rank: the sharded host with its real RCCL collectives (all_to_all_single on packed
+    keys, all_gather_into_tensor on u32 / bytes, MIN all_reduce, the start-up probe, the high-priority communicator) on
+    this single-GPU box -- the calls the driver's multi-GPU run makes, short of a second GPU."""
+    env = dict(os.environ, ANN_SHARD_FORCE_DIST="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29635", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--points", "200000", "--queries", "2000",
+           "--steps", "3", "--warmup", "1", "--data", "randn"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip().startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["config"]["exchange"] == "alltoall" and d["value"] > 0 and d["strong"]["value"] > 0
