@@ -532,13 +532,14 @@ static void launch_codes(const QParams &P, size_t Qhash, const FT *y, u32 *codes
   HIPCHECK(hipGetLastError());
 }
 
-// waves per query: enough slots per wave to amortise the per-wave selection and merge; a shard that owns a
-// small part of the rows gathers few rows per query and is better off with one wave (measured at 1/8: 1.87 -> 1.55 ms)
+// waves per query: enough slots per wave to amortise the per-wave selection and merge; a shard gathers only part of
+// each query's rows and sees G times the queries, and is better off with one wave per query (measured per-rank steps
+// with 4 / 2 / 1 waves: 1.336 / 1.306 / 1.292 ms at 1/2 of the rows, 1.392 / 1.304 / 1.299 ms at 1/4; 1/8: 1.87 -> 1.55)
 static int stage1_waves(u32 P1, double own_frac) {
   int w = (int)(P1 / ANN_S1_CHUNK);
   if (w < 1) w = 1;
   if (w > 4) w = 4;
-  if (own_frac < 0.2) w = 1;
+  if (own_frac <= 0.5) w = 1;
   if (env().s1_waves) w = env().s1_waves;  // ANN_HIP_S1_WAVES; measured at cfg3: 4 = 2 (1.19 ms) < 8 (1.21) < 1 (1.28)
   return w;
 }
