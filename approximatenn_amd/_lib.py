@@ -104,6 +104,9 @@ def load(prec="f32"):
     lib.annhip_stats.argtypes = [vp, C.POINTER(C.c_double * 8), C.c_int]
     lib.annhip_stage_ms.argtypes = [vp, C.POINTER(C.c_double * 6)]
     lib.annhip_cache_clear.argtypes = []
+    lib.annhip_host_profile.argtypes = [C.c_int]
+    lib.annhip_host_stats.restype = C.c_int
+    lib.annhip_host_stats.argtypes = [C.POINTER(SaveT), C.POINTER(C.c_double * 8), C.c_int]
     lib.annhip_cache_drop.argtypes = [C.POINTER(SaveT)]
     lib.annhip_cache_size.restype = sz
     lib.annhip_cache_size.argtypes = []
@@ -129,5 +132,5 @@ EXPORTED = ["gpu_init", "gpu_cleanup", "register_cleanup", "query_gpu", "precomp
             "annhip_sh_final", "annhip_stage1_rows", "annhip_stage2_rows_list", "annhip_exact_select",
             "annhip_recall_ranks", "annhip_profile", "annhip_stats", "annhip_stage_ms",
             "annhip_cache_clear", "annhip_cache_drop", "annhip_cache_size", "annhip_reload_env",
-            "annhip_synth_randnorm", "annhip_synth_reset"]
+            "annhip_synth_randnorm", "annhip_synth_reset", "annhip_host_profile", "annhip_host_stats"]
 DISPATCH_EXPORTED = ["precomp", "query", "free_save"]

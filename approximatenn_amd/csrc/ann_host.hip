@@ -666,7 +666,7 @@ static size_t rows_lds_bytes(const QParams &P, u32 chunk) {
 template <int MODE>
 static void launch_rows(const QParams &P, size_t Q, const FT *y, int alias, const u32 *codes, const u32 *qidx,
                         u32 xbase, size_t nq, u32 len, const u32 *top_i, const FT *top_d, u32 *ids, FT *dist,
-                        unsigned long long *rows_done, hipStream_t s, const u32 *live_rows = NULL) {
+                        unsigned long long *rows_done, hipStream_t s, const u32 *live_rows = NULL, u32 live_off = 0) {
   if (!nq) return;
   // long rows (exact path, a handful of rows) are split over up to 8 workgroups; short rows get one
   const unsigned split = len >= 1024 ? 8 : 1;
@@ -682,7 +682,7 @@ static void launch_rows(const QParams &P, size_t Q, const FT *y, int alias, cons
     allow_lds(row_dists_kernel<DD, MODE>, smem);                                                         \
     hipLaunchKernelGGL((row_dists_kernel<DD, MODE>), dim3(grid, split), dim3(block), smem, s, P, (int)Q, y, \
                        alias, codes, qidx, xbase, len, top_i, top_d, ids, dist, rows_done, live_rows,        \
-                       (u32)nq, chunk);                                                                      \
+                       (u32)nq, chunk, live_off);                                                            \
   } while (0)
   ANN_DISPATCH_D(P.d, CALL);
 #undef CALL
@@ -692,7 +692,8 @@ static void launch_rows(const QParams &P, size_t Q, const FT *y, int alias, cons
 // network + rdups + network on nq rows of reference length L, `len` stored entries, row stride in_stride
 static void launch_exact_select(u32 L, u32 len, u32 in_stride, int k, size_t nq, u32 *ids, FT *dist,
                                 const u32 *qidx, u32 xbase, u32 *out_i, FT *out_d, int ostride, int ooff,
-                                hipStream_t s, const u32 *live_rows = NULL, size_t *out64 = NULL, unsigned max_block = 1024) {
+                                hipStream_t s, const u32 *live_rows = NULL, size_t *out64 = NULL, unsigned max_block = 1024,
+                                u32 live_off = 0) {
   if (!nq) return;
   const int lk = ann_lg(L);
   unsigned npairs = 8u << (lk > 4 ? lk - 4 : 0);
@@ -706,10 +707,10 @@ static void launch_exact_select(u32 L, u32 len, u32 in_stride, int k, size_t nq,
   if (smem <= env().lds_row_max) {  // the whole row in LDS (a CU has 160 KB); longer rows sort in place in HBM
     allow_lds(exact_select_kernel<true>, smem);
     hipLaunchKernelGGL(exact_select_kernel<true>, dim3(grid), dim3(block), smem, s, L, len, in_stride, k,
-                       ids, dist, qidx, xbase, out_i, out_d, ostride, ooff, live_rows, (u32)nq, out64);
+                       ids, dist, qidx, xbase, out_i, out_d, ostride, ooff, live_rows, (u32)nq, out64, live_off);
   } else
     hipLaunchKernelGGL(exact_select_kernel<false>, dim3(grid), dim3(block), 0, s, L, len, in_stride, k,
-                       ids, dist, qidx, xbase, out_i, out_d, ostride, ooff, live_rows, (u32)nq, out64);
+                       ids, dist, qidx, xbase, out_i, out_d, ostride, ooff, live_rows, (u32)nq, out64, live_off);
   HIPCHECK(hipGetLastError());
 }
 
@@ -735,11 +736,21 @@ static long finalize_and_fallback(annhip_index *ix, const QParams &P, size_t Q, 
     hipLaunchKernelGGL(finalize1_kernel, dim3(grid_for(Q, 256, 1u << 30)), dim3(256), 0, s, (int)Q, P.k, K1, P.L1,
                        P.P1, cand_d, cand_i, nvt, top_i, top_d, ostride, ooff, fl, d_fcount, exact_total);
     HIPCHECK(hipGetLastError());
-    if (device_driven && Q <= chunk) {
-      u32 *ids = (u32 *)xids.need(sizeof(u32) * Q * P.Lc1);
-      FT *dist = (FT *)xd.need(sizeof(FT) * Q * P.Lc1);
-      launch_rows<MODE_TABLE>(P, Q, y, alias, codes, fl, 0, Q, P.Lc1, NULL, NULL, ids, dist, rows_done, s, d_fcount);
-      launch_exact_select(P.L1, P.Lc1, P.Lc1, P.k, Q, ids, dist, fl, 0, top_i, top_d, ostride, ooff, s, d_fcount);
+    if (device_driven && Q <= 8 * chunk) {
+      // The workspace holds R = min(Q, chunk) rows; the flagged list is walked in passes of R entries, each pass
+      // device-driven (a pass beyond the device-side count exits at once: two empty launches).  One pass covers
+      // every query batch up to 32k queries at cfg3's row length; cfg4's Q = 100k takes 4, cfg5 (196 KB rows) 2 --
+      // the step stays asynchronous there too (it used to fall back to a host read-back).
+      const size_t R = std::min(Q, chunk);
+      u32 *ids = (u32 *)xids.need(sizeof(u32) * R * P.Lc1);
+      FT *dist = (FT *)xd.need(sizeof(FT) * R * P.Lc1);
+      for (size_t p0 = 0; p0 < Q; p0 += R) {
+        const size_t nq = std::min(R, Q - p0);
+        launch_rows<MODE_TABLE>(P, Q, y, alias, codes, fl + p0, 0, nq, P.Lc1, NULL, NULL, ids, dist, rows_done, s, d_fcount,
+                                (u32)p0);
+        launch_exact_select(P.L1, P.Lc1, P.Lc1, P.k, nq, ids, dist, fl + p0, 0, top_i, top_d, ostride, ooff, s, d_fcount,
+                            NULL, 1024, (u32)p0);
+      }
       return -1;
     }
     HIPCHECK(hipMemcpyAsync(&nflag, d_fcount, sizeof(u32), hipMemcpyDeviceToHost, s));
@@ -1584,6 +1595,24 @@ extern "C" void annhip_cache_drop(const save_t *save) {
 }
 extern "C" size_t annhip_cache_size(void) { return g_cache.size(); }
 
+// Measurement through the host-pointer ABI (tests/harness/time_results): the resident indexes behind
+// query_gpu() record their stage-1 launches like annhip_profile() does; annhip_host_stats() = annhip_stats() of the
+// index resident for `save` (0, or -1 if none), with out[6] = P1 and out[7] = L1 added.
+static bool g_host_profile = false;
+extern "C" void annhip_host_profile(int on) {
+  g_host_profile = on != 0;
+  for (auto &e : g_cache) e.ix->profile = g_host_profile;
+}
+extern "C" int annhip_host_stats(const save_t *save, double out[8], int reset) {
+  for (auto &e : g_cache)
+    if (e.save == save) {
+      annhip_stats(e.ix, out, reset);
+      out[6] = (double)e.ix->P1, out[7] = (double)e.ix->L1;
+      return 0;
+    }
+  return -1;
+}
+
 static bool same_key(const CacheEntry &e, const save_t *sv, const ftype *points) {
   return e.save == sv && e.points == points;
 }
@@ -1602,6 +1631,7 @@ static void cache_put(const save_t *sv, const ftype *points, u64 fp, annhip_inde
     annhip_index_destroy(g_cache.front().ix);
     g_cache.erase(g_cache.begin());
   }
+  ix->profile = g_host_profile;
   g_cache.push_back(CacheEntry{sv, points, sv->graph, sv->n, sv->k, sv->d_long, sv->tries, fp, ix});
 }
 

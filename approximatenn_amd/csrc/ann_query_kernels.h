@@ -900,11 +900,12 @@ __global__ __launch_bounds__(256) void row_dists_kernel(QParams P, int Q, const 
                                                         FT *__restrict__ dist_out,
                                                         unsigned long long *__restrict__ rows_done,
                                                         const u32 *__restrict__ live_rows, u32 nrows,
-                                                        u32 chunk) {
+                                                        u32 chunk, u32 live_off) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // Device-driven launches (live_rows != NULL) use a small persistent grid that walks the device-side row
   // count: launching one workgroup per POSSIBLE row just to exit cost ~50 us per launch at Q = 10k.
-  if (live_rows) nrows = min(nrows, *live_rows);
+  // live_off: this launch covers entries [live_off, live_off + nrows) of the counted list (bounded workspace).
+  if (live_rows) nrows = min(nrows, max(*live_rows, live_off) - live_off);
   const int lane = lane_id(), w = threadIdx.x >> 6, W = blockDim.x >> 6;
   for (u32 row = blockIdx.x; row < nrows; row += gridDim.x) {
   const u32 x = qidx ? qidx[row] : xbase + row;
@@ -1045,9 +1046,9 @@ __global__ __launch_bounds__(1024) void exact_select_kernel(u32 L, u32 len, u32 
                                                            u32 *__restrict__ out_id,
                                                            FT *__restrict__ out_dist, int ostride,
                                                            int ooff, const u32 *__restrict__ live_rows,
-                                                           u32 nrows, size_t *__restrict__ out64) {
+                                                           u32 nrows, size_t *__restrict__ out64, u32 live_off) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  if (live_rows) nrows = min(nrows, *live_rows);  // persistent grid over the device-side row count
+  if (live_rows) nrows = min(nrows, max(*live_rows, live_off) - live_off);  // persistent grid over the device-side row count
   for (u32 row = blockIdx.x; row < nrows; row += gridDim.x) {
   const u32 x = qidx ? qidx[row] : xbase + row;
   u32 *gi = ids_in + (size_t)row * in_stride;

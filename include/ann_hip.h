@@ -196,6 +196,11 @@ void annhip_stats(annhip_index *ix, double out[8], int reset);
 /* While profiling, annhip_query also drops HIP events at its stage boundaries; out[0..5] = accumulated ms of
  * hash codes, stage-1 kernel, finalize + exact fallback, stage-2 rows, stage-2 network, id widening. */
 void annhip_stage_ms(annhip_index *ix, double out[6]);
+/* The same through the host-pointer ABI: annhip_host_profile(1) makes the indexes resident behind query_gpu() /
+ * precomp_gpu() record their stage-1 launches; annhip_host_stats() = annhip_stats() of the index resident for `save`
+ * plus out[6] = P1, out[7] = L1 (returns 0, or -1 when no index is resident for it). */
+void annhip_host_profile(int on);
+int annhip_host_stats(const save_t *save, double out[8], int reset);
 
 #ifdef __cplusplus
 }

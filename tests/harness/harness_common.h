@@ -21,7 +21,7 @@ extern size_t *oracle_query(const save_t *save, const ftype *points, size_t ycnt
 extern void oracle_gen_rand(size_t count, ftype *out);
 
 typedef struct {
-  size_t n, k, d, tries, reps, ycnt, rb, rlenb, ra, rlena;
+  size_t n, k, d, tries, reps, ycnt, rb, rlenb, ra, rlena, cpu_queries;
   unsigned seed;
   int verbose, use_y, use_cpu, save_test, lanes;
 } opts_t;
@@ -33,11 +33,13 @@ static void usage(const char *prog) {
           "\t-b/-s pre-Walsh rotation count/size (6/1)  -a/-r post-Walsh rotation count/size (1/1)\n"
           "\t-y query count  -z (compare: -y 50; time: save the index)  -c CPU column only  -v verbose\n"
           "\t-S seed for srandom() (12345; the reference seeds with time(NULL))\n"
-          "\t-P lanes (time_results only): also time the pipelined host API (annhip_stream_*) with that many lanes\n", prog);
+          "\t-P lanes (time_results only): also time the pipelined host API (annhip_stream_*) with that many lanes\n"
+          "\t-C queries (time_results only): size of the batch the CPU column is timed on (default: -y for the oracle,\n"
+          "\t   128 for the reference's query_cpu)\n", prog);
 }
 
 static opts_t parse_opts(int argc, char **argv, const char *letters, size_t default_reps) {
-  opts_t o = {1000, 10, 80, 10, default_reps, 0, 6, 1, 1, 1, 12345u, 0, 0, 0, 0, 0};
+  opts_t o = {1000, 10, 80, 10, default_reps, 0, 6, 1, 1, 1, 0, 12345u, 0, 0, 0, 0, 0};
   int c;
   opterr = 0;
   while ((c = getopt(argc, argv, letters)) != -1) switch (c) {
@@ -56,6 +58,7 @@ static opts_t parse_opts(int argc, char **argv, const char *letters, size_t defa
       case 'v': o.verbose = 1; break;
       case 'c': o.use_cpu = 1; break;
       case 'P': o.lanes = (int)strtol(optarg, NULL, 0); break;
+      case 'C': o.cpu_queries = strtoul(optarg, NULL, 0); break;
       default: usage(argv[0]); exit(c == 'h' ? 0 : 2);
     }
   return o;

@@ -145,10 +145,13 @@ def test_residency_cache_detects_changed_content():
     A._lib.load("f32").annhip_cache_clear()
 
 
+@pytest.mark.parametrize("exact_bytes", ["20000", "100000"])
 @pytest.mark.parametrize("prec", ["f32", "f64"])
-def test_network_in_hbm_and_chunked_host_driven_exact_path(prec, monkeypatch):
+def test_network_in_hbm_and_chunked_host_driven_exact_path(prec, exact_bytes, monkeypatch):
     """Paths that only very large shapes reach (full-size cfg5 rows do not fit LDS; cfg4's Q=100k exceeds the exact
-    path's workspace budget): force them with the size hooks on a ties-heavy dataset, in both path modes."""
+    path's workspace budget): force them with the size hooks on a ties-heavy dataset, in both path modes.
+    exact_bytes 20000: a workspace of a few rows, batch > 8 workspaces => host-driven chunks; 100000: ~20 rows =>
+    the device-driven path walks the flagged list in several passes over the bounded workspace."""
     orc = O.CpuBackend(prec, "oracle")
     O.srandom(77)
     orc.rand_norm_reset()
@@ -159,7 +162,7 @@ def test_network_in_hbm_and_chunked_host_driven_exact_path(prec, monkeypatch):
     o_ids, o_d, o_save = orc.precomp(pts, 6, 4)
     want = orc.query(o_save, pts, y)
     monkeypatch.setenv("ANN_HIP_LDS_ROW_MAX", "64")              # every exact-path row sorts in HBM
-    monkeypatch.setenv("ANN_HIP_EXACT_BYTES", "20000")           # a few rows per chunk, host-driven
+    monkeypatch.setenv("ANN_HIP_EXACT_BYTES", exact_bytes)
     for exact in (False, True):
         if exact:
             monkeypatch.setenv("ANN_HIP_EXACT", "1")
