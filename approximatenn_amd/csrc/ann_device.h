@@ -135,6 +135,53 @@ __device__ inline int wave_select_smallest(const Key *buf, int cnt, int want, Ke
   return m;
 }
 
+// ------------------------------------------------------------------ wave-resident top-K
+// An ascending list of the (up to 64) smallest DISTINCT keys seen so far lives in ONE register per lane: lane i holds
+// the i-th smallest, key_max() where there is none yet.  Inserting a wave-uniform key is a compare, a one-lane wave
+// shift (DPP wave_shr:1 -- no LDS crossbar) and two selects; the K-th smallest (the admission threshold) is a
+// v_readlane.  Replaces an LDS candidate buffer + periodic K-pass selection where K <= 64.
+__device__ __forceinline__ u32 lane_prev_u32(u32 v) {  // value of lane i-1; lane 0 gets 0
+  return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+}
+#ifdef USE_FLOAT
+__device__ __forceinline__ Key key_lane_prev(Key k) {
+  return ((u64)lane_prev_u32((u32)(k >> 32)) << 32) | lane_prev_u32((u32)k);
+}
+__device__ __forceinline__ Key key_readlane(Key k, int src) {  // src wave-uniform
+  return ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(k >> 32), src) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)k, src);
+}
+#else
+__device__ __forceinline__ Key key_lane_prev(Key k) {
+  Key o;
+  o.d = ((u64)lane_prev_u32((u32)(k.d >> 32)) << 32) | lane_prev_u32((u32)k.d);
+  o.i = lane_prev_u32((u32)k.i);
+  return o;
+}
+__device__ __forceinline__ Key key_readlane(Key k, int src) {
+  Key o;
+  o.d = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(k.d >> 32), src) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)k.d, src);
+  o.i = (u32)__builtin_amdgcn_readlane((int)(u32)k.i, src);
+  return o;
+}
+#endif
+__device__ __forceinline__ void wave_topk_insert(Key &mine, Key k) {  // k wave-uniform
+  if (__ballot(key_eq(mine, k))) return;  // already listed (the same point reached through another bucket)
+  const Key up = key_lane_prev(mine);     // lane 0 sees the zero key
+  if (key_less(k, mine)) mine = key_less(k, up) ? up : k;
+}
+// Offer the keys of the lanes in `mm` (a ballot) to the list; tau = current K1-th smallest (admission threshold).
+__device__ __forceinline__ void wave_topk_offer(Key &mine, Key &tau, Key key, u64 mm, int K1) {
+  while (mm) {
+    const int src = __builtin_ctzll(mm);
+    mm &= mm - 1;
+    const Key k = key_readlane(key, src);
+    if (key_less(k, tau)) {
+      wave_topk_insert(mine, k);
+      tau = key_readlane(mine, K1 - 1);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ row layout for power-of-two d
 // A row of D elements is read by LPR lanes as C chunks of 16 bytes per lane; lane position p reads
 // chunks p, p+LPR, ... so that every load instruction covers whole contiguous 128-byte pieces.

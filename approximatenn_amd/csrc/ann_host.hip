@@ -626,11 +626,11 @@ static void launch_stage1(annhip_index *ix, const QParams &P, size_t Q, const FT
 }
 
 template <int DD>
-static void launch_bucket_d(const QParams &P, size_t nbuckets, int W, int K1, int cap, u32 list_cap, size_t smem, FT *cand_d,
+static void launch_bucket_d(const QParams &P, size_t nbuckets, int W, int K1, u32 list_cap, size_t smem, FT *cand_d,
                             u32 *cand_i, u32 *nvt, u32 *nvo, hipStream_t s) {
   if constexpr (DD > 0) {
     allow_lds(stage1_bucket_kernel<DD>, smem);
-    hipLaunchKernelGGL(stage1_bucket_kernel<DD>, dim3((unsigned)nbuckets), dim3(64 * W), smem, s, P, K1, cap, list_cap, cand_d,
+    hipLaunchKernelGGL(stage1_bucket_kernel<DD>, dim3((unsigned)nbuckets), dim3(64 * W), smem, s, P, K1, list_cap, cand_d,
                        cand_i, nvt, nvo);
   }
 }
@@ -639,17 +639,17 @@ static void launch_bucket_d(const QParams &P, size_t nbuckets, int W, int K1, in
 static bool launch_stage1_bucket(const QParams &P, const TryInfo &one, size_t nbuckets, FT *cand_d, u32 *cand_i, u32 *nvt,
                                  u32 *nvo, hipStream_t s) {
   if (!d_is_fast(P.d) || env().point_precomp) return false;
-  const int K1 = P.k + 1, W = 4;
-  int cap = K1 + 2 * 16;  // room for one pass of up to RPW = 16 keys after a shrink
-  cap = (cap + 7) & ~7;
-  const size_t tile = sizeof(VT) * (size_t)ANN_BK_TILE_ROWS * (P.d / ANN_VEC + 1);
+  const int K1 = P.k + 1, W = ANN_BK_WAVES;
+  if (K1 > ANN_WAVE) return false;  // the wave-resident selection holds one key per lane
+  const size_t ch = P.d / ANN_VEC, trows = std::max<size_t>(ANN_BK_TILE_CHUNKS / ch, 8);
+  const size_t tile = sizeof(VT) * trows * (ch + 1);
   if (P.ds + 1 > ANN_BK_MAX_RUNS) return false;
   const u32 list_cap = std::min<u32>(P.P1, (u32)(P.ds + 1) * one.pm);
-  const size_t smem = tile + sizeof(Key) * (size_t)one.pm * cap + sizeof(Key) * (size_t)W * K1 + sizeof(Key) * (size_t)one.pm +
-                      sizeof(u32) * (size_t)list_cap + sizeof(int) * (size_t)one.pm + sizeof(u32) * (ANN_BK_MAX_RUNS + 1) + 16;
+  const size_t smem = tile + sizeof(Key) * (size_t)one.pm * K1 + sizeof(u32) * (size_t)list_cap +
+                      sizeof(u32) * (ANN_BK_MAX_RUNS + 1) + 16;
   if (smem > 80 * 1024) return false;  // keep two workgroups per CU
   if ((u32)P.k > P.P1) return false;
-#define CALL(DD) launch_bucket_d<DD>(P, nbuckets, W, K1, cap, list_cap, smem, cand_d, cand_i, nvt, nvo, s)
+#define CALL(DD) launch_bucket_d<DD>(P, nbuckets, W, K1, list_cap, smem, cand_d, cand_i, nvt, nvo, s)
   ANN_DISPATCH_D2(P.d, CALL);
 #undef CALL
   HIPCHECK(hipGetLastError());

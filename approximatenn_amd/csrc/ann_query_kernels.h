@@ -726,10 +726,25 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
 // stage1_select with alias = 1 (self excluded); nv_tot is exact here (valid slots minus the member itself).
 // Host-side conditions (else the per-point kernel is used): power-of-two d, pm members' selection state + one tile
 // fit LDS.
-#define ANN_BK_TILE_ROWS 32  // measured at cfg3: 16 -> 0.89 s, 32 -> 0.92 s, 64 -> 1.17 s, 128 -> 1.54 s of precomp (occupancy beats fewer barriers)
+// One tile = ANN_BK_TILE_CHUNKS 16-byte chunks of candidate rows (16 KB: 32 rows at d = 128 float).
+// What bounds this kernel is the LDS, not HBM (counters, round 2: LDS busy 66 % of the kernel, waves 60 % waiting):
+//  * each member's running selection is a wave-resident top-K (ann_device.h: one key per lane, DPP shift insert) --
+//    the LDS candidate buffer and its K-pass shrink (132 LDS-crossbar shuffles each) are gone; between tiles the
+//    list rests in LDS (K1 keys per member).
+// (Double-buffering the tile was tried and is slower: 0.72 -> 0.92 s at cfg3 -- occupancy matters more here.)
+#ifndef ANN_BK_TILE_CHUNKS
+#define ANN_BK_TILE_CHUNKS 1024
+#endif
+#ifndef ANN_BK_MEMBERS
+#define ANN_BK_MEMBERS 1  // members scored per pass over the tile (measured at cfg3: 1 -> 0.53 s, 2 -> 0.57, 3 -> 0.72, 4 -> 0.77:
+                          // fewer LDS reads per distance do not pay once the selection is out of the LDS; balance and occupancy do)
+#endif
+#ifndef ANN_BK_WAVES
+#define ANN_BK_WAVES 4
+#endif
 #define ANN_BK_MAX_RUNS 64
 template <int D>
-__global__ __launch_bounds__(256) void stage1_bucket_kernel(QParams P, int K1, int cap, u32 list_cap,
+__global__ __launch_bounds__(64 * ANN_BK_WAVES) void stage1_bucket_kernel(QParams P, int K1, u32 list_cap,
                                                             FT *__restrict__ cand_dist, u32 *__restrict__ cand_id,
                                                             u32 *__restrict__ nv_tot, u32 *__restrict__ nv_own) {
   typedef RowLay<D> L;
@@ -739,21 +754,17 @@ __global__ __launch_bounds__(256) void stage1_bucket_kernel(QParams P, int K1, i
   const u32 b = blockIdx.x, pm = tr.pm;
   const u32 members = tr.seg[b].y;  // valid ids of this bucket (in precomp the owned range is everything)
   if (members == 0) return;
-  constexpr int ROWV = D / ANN_VEC + 1;  // tile row stride in 16-byte units (+1: spreads rows over LDS banks)
+  constexpr int CH = D / ANN_VEC;        // chunks per row
+  constexpr int ROWV = CH + 1;           // tile row stride in 16-byte units (+1: spreads rows over LDS banks)
+  constexpr int TROWS = ANN_BK_TILE_CHUNKS / CH >= 8 ? ANN_BK_TILE_CHUNKS / CH : 8;  // rows per tile (>= one wave pass)
   unsigned char *sp = smem;
-  VT *tile = reinterpret_cast<VT *>(sp);                 sp += sizeof(VT) * (size_t)ANN_BK_TILE_ROWS * ROWV;
-  Key *kbuf_all = reinterpret_cast<Key *>(sp);           sp += sizeof(Key) * (size_t)pm * cap;
-  Key *kout_all = reinterpret_cast<Key *>(sp);           sp += sizeof(Key) * (size_t)W * K1;
-  Key *tau_all = reinterpret_cast<Key *>(sp);            sp += sizeof(Key) * (size_t)pm;
+  VT *tile = reinterpret_cast<VT *>(sp);                 sp += sizeof(VT) * (size_t)TROWS * ROWV;
+  Key *klist = reinterpret_cast<Key *>(sp);              sp += sizeof(Key) * (size_t)pm * K1;  // per member: its K1 best so far
   u32 *clist = reinterpret_cast<u32 *>(sp);              sp += sizeof(u32) * (size_t)list_cap;  // candidate ids, slot order
-  int *kcnt_all = reinterpret_cast<int *>(sp);           sp += sizeof(int) * (size_t)pm;
   u32 *roff = reinterpret_cast<u32 *>(sp);               sp += sizeof(u32) * (ANN_BK_MAX_RUNS + 1);
   const u32 *mem_ids = tr.tab + (size_t)b * pm;  // members, descending ids
   const u32 ds1 = (u32)P.ds + 1u;
-  for (u32 m = threadIdx.x; m < members; m += blockDim.x) {
-    kcnt_all[m] = 0;
-    tau_all[m] = key_max();
-  }
+  for (u32 e = threadIdx.x; e < members * (u32)K1; e += blockDim.x) klist[e] = key_max();
   // valid ids of every run below P1 (the first seg.y entries of the neighbour bucket's row): counts, then offsets
   if (threadIdx.x < ds1) {
     const u32 yy = threadIdx.x, start = yy * pm;
@@ -777,26 +788,31 @@ __global__ __launch_bounds__(256) void stage1_bucket_kernel(QParams P, int K1, i
   __syncthreads();
 
   const int p = lane % L::LPR, g = lane / L::LPR;
-  for (u32 r0 = 0; r0 < total; r0 += ANN_BK_TILE_ROWS) {
-    const u32 rows = min((u32)ANN_BK_TILE_ROWS, total - r0);
+  for (u32 r0 = 0; r0 < total; r0 += TROWS) {
+    const u32 rows = min((u32)TROWS, total - r0);
     if (r0) __syncthreads();  // previous tile fully consumed
-    // stage `rows` candidate rows: LPR lanes per row, whole 128-byte pieces per load instruction
-    for (u32 r = (u32)(threadIdx.x / L::LPR); r < rows; r += blockDim.x / L::LPR) {
-      const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)clist[r0 + r] * D) + p;
-#pragma unroll
-      for (int c = 0; c < L::C; c++) tile[(size_t)r * ROWV + p + c * L::LPR] = load_row_chunk<true>(rp + c * L::LPR);
+    for (u32 e = threadIdx.x; e < rows * CH; e += blockDim.x) {  // whole 128-byte pieces per load instruction
+      const u32 r = e / CH, c = e - r * CH;
+      tile[(size_t)r * ROWV + c] = load_row_chunk<true>(reinterpret_cast<const VT *>(P.points + (size_t)clist[r0 + r] * D) + c);
     }
     __syncthreads();
-    // every wave scores its members against the tile
-    for (u32 m = w; m < members; m += W) {
-      const u32 x = mem_ids[m];
-      VT a[L::C];
-      const VT *yp = reinterpret_cast<const VT *>(P.points + (size_t)x * D) + p;
+    // every wave scores its members, NM at a time, against the tile (a missing member of the last group repeats the
+    // group's first one and is masked out)
+    constexpr int NM = ANN_BK_MEMBERS;
+    for (u32 m0 = (u32)NM * w; m0 < members; m0 += (u32)NM * W) {
+      u32 mi[NM], xi[NM];
+      VT a[NM][L::C];
+      Key mine[NM], tau[NM];
 #pragma unroll
-      for (int c = 0; c < L::C; c++) a[c] = yp[c * L::LPR];
-      SelState S;
-      S.kbuf = kbuf_all + (size_t)m * cap, S.kout = kout_all + (size_t)w * K1;
-      S.kcnt = kcnt_all[m], S.K1 = K1, S.cap = cap, S.tau = tau_all[m];
+      for (int j = 0; j < NM; j++) {
+        mi[j] = m0 + j < members ? m0 + j : m0;
+        xi[j] = mem_ids[mi[j]];
+        const VT *yp = reinterpret_cast<const VT *>(P.points + (size_t)xi[j] * D) + p;
+#pragma unroll
+        for (int c = 0; c < L::C; c++) a[j][c] = yp[c * L::LPR];
+        mine[j] = lane < K1 ? klist[(size_t)mi[j] * K1 + lane] : key_max();
+        tau[j] = key_readlane(mine[j], K1 - 1);
+      }
       for (u32 base = 0; base < rows; base += L::RPW) {
         const u32 r = base + g;
         const bool inb = r < rows;
@@ -805,38 +821,33 @@ __global__ __launch_bounds__(256) void stage1_bucket_kernel(QParams P, int K1, i
         const VT *tp = tile + (size_t)(inb ? r : base) * ROWV + p;
 #pragma unroll
         for (int c = 0; c < L::C; c++) bv[c] = tp[c * L::LPR];
-        const FT dist = row_reduce<D, ROW_SQDIFF>(a, bv);
-        const Key key = key_make(dist, id);
-        const bool pass = inb && id != x && p == 0 && key_less(key, S.tau);
-        const u64 mm = __ballot(pass);
-        if (mm) {
-          if (pass) S.kbuf[S.kcnt + mask_rank(mm)] = key;
-          S.kcnt += __popcll(mm);
-          if (S.kcnt + L::RPW > S.cap) sel_shrink(S);
+        const bool ok = inb && p == 0;
+#pragma unroll
+        for (int j = 0; j < NM; j++) {
+          const Key key = key_make(row_reduce<D, ROW_SQDIFF>(a[j], bv), id);
+          const u64 mm = __ballot(ok && (j == 0 || m0 + j < members) && id != xi[j] && key_less(key, tau[j]));
+          if (mm) wave_topk_offer(mine[j], tau[j], key, mm, K1);
         }
       }
-      wave_lds_sync();
-      if (lane == 0) {
-        kcnt_all[m] = S.kcnt;
-        tau_all[m] = S.tau;
+      if (lane < K1) {
+#pragma unroll
+        for (int j = 0; j < NM; j++)
+          if (j == 0 || m0 + j < members) klist[(size_t)mi[j] * K1 + lane] = mine[j];
       }
     }
   }
   __syncthreads();
-  // final selection per member
-  for (u32 m = w; m < members; m += W) {
-    const u32 x = mem_ids[m];
-    Key *kout = kout_all + (size_t)w * K1;
-    const int got = wave_select_smallest(kbuf_all + (size_t)m * cap, kcnt_all[m], K1, kout);
-    for (int i = lane; i < K1; i += ANN_WAVE) {
-      cand_dist[(size_t)x * K1 + i] = i < got ? key_dist(kout[i]) : ft_inf();
-      cand_id[(size_t)x * K1 + i] = i < got ? key_id(kout[i]) : ANN_ID_NONE;
-    }
-    if (lane == 0) {
+  // results: each member's list is already ascending and distinct
+  for (u32 e = threadIdx.x; e < members * (u32)K1; e += blockDim.x) {
+    const u32 m = e / K1, i = e - m * K1, x = mem_ids[m];
+    const Key kk = klist[e];
+    const bool have = !key_eq(kk, key_max());
+    cand_dist[(size_t)x * K1 + i] = have ? key_dist(kk) : ft_inf();
+    cand_id[(size_t)x * K1 + i] = have ? key_id(kk) : ANN_ID_NONE;
+    if (i == 0) {
       nv_tot[x] = total - 1u;  // the member itself sits in its own bucket's run, below P1
       nv_own[x] = total - 1u;
     }
-    wave_lds_sync();
   }
 }
 
