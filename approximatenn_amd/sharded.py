@@ -33,7 +33,9 @@ Streams: with submit()/collect() two batches are in flight.  All stage-1 gathers
 normal-priority HIP stream; everything else of a batch (hash, merges, stage 2, networks, the collectives' glue) runs on
 the batch's own HIGH-priority stream, so the small latency-bound kernels and the exchanges of batch i slip in
 underneath the HBM-bound gather of batch i+1 instead of queueing behind it (two gathers running concurrently only
-slow each other down -- measured).
+slow each other down -- measured).  Collectives execute in ISSUE order on the communicator's single stream, so a batch
+is issued in two halves and submit(i+1) issues [hash, codes all-gather, gather] of batch i+1 BEFORE the exchanges of
+batch i (which all wait for gather i): otherwise gather(i+1) would start only when batch i is nearly done.
 
 If the backend cannot do all_to_all_single the same steps run with an all-gather + local slice instead
 (exchange="allgather": G times the traffic, identical results); the choice is agreed on by all ranks at start-up.
@@ -152,7 +154,7 @@ class _Lane:
     """Buffers + stream of one in-flight batch.  Everything is allocated once per batch size: no per-step tensors."""
 
     def __init__(self, stream):
-        self.stream, self.shape, self.busy, self.event = stream, None, False, None
+        self.stream, self.shape, self.busy, self.event, self.need_back = stream, None, False, None, False
 
     def ensure(self, eng, y, G, qs, fcap):
         Q = y.shape[0]
@@ -280,6 +282,11 @@ class ShardedQuery:
         return t
 
     # ------------------------------------------------------------------ one step
+    # A batch is enqueued in two halves.  FRONT = hash, all-gather of the codes, the stage-1 gather; BACK = everything
+    # behind the gather (exchanges, merges, exact path, stage 2, networks).  All collectives of a process group run in
+    # ISSUE order on the communicator's one stream, and every collective of BACK(i) waits for gather(i): had BACK(i)
+    # been issued before FRONT(i+1), the codes all-gather of batch i+1 would sit behind it and gather(i+1) could not
+    # start before batch i was nearly done.  So submit(i+1) issues FRONT(i+1) first and only then BACK(i).
     def submit(self, y, alias=False):
         """Enqueue one batch (y: [Q,d], identical on every rank).  Returns a ticket for collect()."""
         e, G, r = self.eng, self.world, self.rank
@@ -291,18 +298,15 @@ class ShardedQuery:
             if self._gather_stream is None:
                 self._gather_stream = e.new_stream(y.device, reserve_cus=self.reserve_cus)
         Q = y.shape[0]
-        qs = (Q + G - 1) // G
-        q_lo = r * qs
+        L.y, L.alias, L.Q, L.qs = y, alias, Q, (Q + G - 1) // G
+        L.q_lo = r * L.qs
         if L.stream is not None:
             L.stream.wait_stream(torch.cuda.current_stream(y.device))   # y was produced on the caller's stream
         with e.use(L.stream):
-            L.ensure(e, y, G, qs, self.fcap)
-            e.sh_codes(y, q_lo, q_lo + qs, L.codes_slice)
+            L.ensure(e, y, G, L.qs, self.fcap)
+            e.sh_codes(y, L.q_lo, L.q_lo + L.qs, L.codes_slice)
             self._gather_cat(L.codes_all, L.codes_slice)
-            if self.exact_all:
-                L.top_all.fill_(ID_FLAG - (1 << 32))                     # every query takes the exact path
-                L.top_i.fill_(ID_FLAG - (1 << 32))
-            else:
+            if not self.exact_all:
                 gs = self._gather_stream if L.stream is not None else None
                 if gs is not None:
                     gs.wait_event(e.event(L.stream))
@@ -310,6 +314,22 @@ class ShardedQuery:
                     e.sh_stage1(y, alias, L.codes_all, L.keys, L.nvalid, L.nown)
                 if gs is not None:
                     L.stream.wait_event(e.event(gs))
+        L.busy, L.need_back = True, True
+        for P in self._lanes:                                            # the batch submitted before this one
+            if P is not L and P.busy and P.need_back:
+                self._back(P)
+        t = self._next
+        self._tickets[t] = L
+        self._next += 1
+        return t
+
+    def _back(self, L):
+        e, G, Q, qs, q_lo, y, alias = self.eng, self.world, L.Q, L.qs, L.q_lo, L.y, L.alias
+        with e.use(L.stream):
+            if self.exact_all:
+                L.top_all.fill_(ID_FLAG - (1 << 32))                     # every query takes the exact path
+                L.top_i.fill_(ID_FLAG - (1 << 32))
+            else:
                 self._to_owner(L.keys_in, L.keys)
                 e.sh_merge_finalize(G, Q, q_lo, qs, L.keys_in, L.nvalid, L.top_i, L.top_d)
                 self._gather_cat(L.top_all, L.top_i)
@@ -329,16 +349,14 @@ class ShardedQuery:
             if L.stream is not None:
                 L.event = torch.cuda.Event()
                 L.event.record(L.stream)
-        L.busy, L.y, L.alias, L.Q = True, y, alias, Q
-        t = self._next
-        self._tickets[t] = L
-        self._next += 1
-        return t
+        L.need_back = False
 
     def collect(self, ticket):
         """Wait for the batch, repair flagged queries if there are any, return (ids int64 [Q,k], sq. distances [Q,k])."""
         e = self.eng
         L = self._tickets.pop(ticket)
+        if L.need_back:                       # no later batch was submitted: its second half is still to be issued
+            self._back(L)
         if L.event is not None:
             L.event.synchronize()
         nf = int(L.head_host[0])              # flagged queries the device-driven exact path had no room for; the same
