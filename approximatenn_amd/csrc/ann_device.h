@@ -264,9 +264,34 @@ template <int D>
 struct RowChunks<D, true> {
   static constexpr int C = RowLay<D>::C;
 };
+// D < 0 encodes this layout: -D = 16*OC + C.  OC = 0: `oc` comes at run time (any odd-factor count up to 64, tail by
+// shuffles).  OC in {3, 5}: `oc` is static, the groups of OC lanes sit inside the 16-lane DPP rows (16/OC groups per
+// row, the remaining lanes idle) and the whole tail is unrolled at compile time with DPP row shifts -- no LDS crossbar,
+// no run-time control flow (the reference drivers' default d = 80 is OC = 5: C = 4 float chunks / 8 double chunks).
+template <int D>
+struct OcCode {
+  static constexpr int C = D < 0 ? ((-D) % 16) : 1;
+  static constexpr int OC = D < 0 ? ((-D) / 16) : 0;
+};
 template <int D>
 struct RowChunks<D, false> {
-  static constexpr int C = D < 0 ? -D : 1;
+  static constexpr int C = OcCode<D>::C;
+};
+// lane -> (row of the wave pass, position in the row's lane group) for the layout encoded by D < 0
+template <int D>
+struct OcLanes {
+  int oc, rpw, g, p;
+  bool valid;
+  __device__ __forceinline__ OcLanes(int d, int lane) {
+    constexpr int C = OcCode<D>::C, OC = OcCode<D>::OC;
+    if constexpr (OC > 0) {
+      constexpr int GPR = 16 / OC;  // groups per 16-lane DPP row
+      const int l = lane & 15;
+      oc = OC, rpw = 4 * GPR, g = (lane >> 4) * GPR + l / OC, p = l % OC, valid = l < GPR * OC;
+    } else {
+      oc = d / (ANN_VEC * C), rpw = ANN_WAVE / oc, g = lane / oc, p = lane - g * oc, valid = g < rpw;
+    }
+  }
 };
 
 // v[r] of lane `src`, r wave-uniform.  Written as a uniform switch (one shuffle per case): a select chain over the
@@ -286,7 +311,39 @@ __device__ __forceinline__ FT shfl_reg(const FT (&v)[ANN_VEC], int r, int src) {
   return o;
 }
 
-template <int C, int MODE>
+// Static tail: the literal tree (compute.cl:160-167) over S values, value z = VEC*p + j in e[j] of lane p, one level per
+// template instance; the partner z + h lives in lane p + (j+h)/VEC, register (j+h)%VEC -- both compile-time constants.
+template <int MODE, int S, int J>
+__device__ __forceinline__ void oc_tail_elem(const FT (&old)[ANN_VEC], FT (&e)[ANN_VEC], int p, FT g) {
+  constexpr int h = S >> 1, hh = J + h, off = hh / ANN_VEC, reg = hh % ANN_VEC;
+  const FT zero = 0;
+  FT o;
+  if constexpr (off == 0) o = old[reg]; else o = lane_up<off>(old[reg]);
+  const int z = ANN_VEC * p + J;
+  if (z < h) e[J] = old[J] + (o + ((z == 0) ? g : zero));  // positions >= h are only read at this level
+}
+template <int MODE, int S>
+__device__ __forceinline__ void oc_tail(FT (&e)[ANN_VEC], int p) {
+  if constexpr ((S >> 1) > 0) {
+    FT old[ANN_VEC];
+#pragma unroll
+    for (int j = 0; j < ANN_VEC; j++) old[j] = e[j];
+    FT g = 0;
+    if constexpr (S & 1) {  // g = m[S-1], added into z == 0 only
+      constexpr int zz = S - 1, goff = zz / ANN_VEC, greg = zz % ANN_VEC;
+      if constexpr (goff == 0) g = old[greg]; else g = lane_up<goff>(old[greg]);
+    }
+    oc_tail_elem<MODE, S, 0>(old, e, p, g);
+    oc_tail_elem<MODE, S, 1>(old, e, p, g);
+#if ANN_VEC > 2
+    oc_tail_elem<MODE, S, 2>(old, e, p, g);
+    oc_tail_elem<MODE, S, 3>(old, e, p, g);
+#endif
+    oc_tail<MODE, (S >> 1)>(e, p);
+  }
+}
+
+template <int C, int MODE, int OC = 0>
 __device__ __forceinline__ FT row_reduce_oc(const VT (&a)[C], const VT (&b)[C], int oc, int p) {
   FT e[C][ANN_VEC];
 #pragma unroll
@@ -312,6 +369,10 @@ __device__ __forceinline__ FT row_reduce_oc(const VT (&a)[C], const VT (&b)[C], 
       for (int j = 0; j < ANN_VEC; j++)
         e[c][j] = (MODE == ROW_PRODUCT) ? e[c][j] + (e[c + h][j] + zero) : e[c][j] + e[c + h][j];
   // tail: literal tree (compute.cl:160-167) over m = oc*VEC values, value z = VEC*p + j lives in e[0][j] of lane p
+  if constexpr (OC > 0) {
+    oc_tail<MODE, OC * ANN_VEC>(e[0], p);
+    return e[0][0];
+  }
   const int lane = lane_id();
   for (int s = oc * ANN_VEC; s >> 1; s >>= 1) {
     const int h = s >> 1;

@@ -450,14 +450,16 @@ extern "C" void annhip_index_export(const annhip_index *ix, save_t *save) {
 }
 
 // ----------------------------------------------------------------------------- launchers
-// Row layouts (ann_device.h): D > 0 = power of two (RowLay<D>); D = -C = d/VEC is oc * C chunks, C = 2^a <= 8, oc <= 64
-// lanes per row (row_reduce_oc; e.g. the reference drivers' default d = 80); D = 0 = any d (literal tree through LDS).
+// Row layouts (ann_device.h): D > 0 = power of two (RowLay<D>); D < 0: d/VEC is oc * C chunks, C = 2^a <= 8, oc <= 64
+// lanes per row (row_reduce_oc), -D = 16*OC + C with OC = oc where the layout is static (oc = 3 or 5, e.g. the reference
+// drivers' default d = 80) and OC = 0 where oc comes at run time; D = 0 = any d (literal tree through LDS).
 static int layout_code(size_t d, bool allow_oc = true) {
   if (d >= 16 && (d & (d - 1)) == 0 && d <= (sizeof(FT) == 4 ? 1024u : 512u)) return (int)d;
   if (allow_oc && d % ANN_VEC == 0) {
     size_t nc = d / ANN_VEC, C = 1;
     while (C < 8 && nc % (2 * C) == 0) C *= 2;
     const size_t oc = nc / C;
+    if ((oc == 3 || oc == 5) && C >= 2) return -(int)(16 * oc + C);  // static layout, DPP-only tail (d = 80: oc = 5)
     if (oc >= 2 && oc <= 64) return -(int)C;
   }
   return 0;
@@ -475,6 +477,12 @@ static int layout_code(size_t d, bool allow_oc = true) {
     case -2: CALL(-2); break;         \
     case -4: CALL(-4); break;         \
     case -8: CALL(-8); break;         \
+    case -50: CALL(-50); break;       \
+    case -52: CALL(-52); break;       \
+    case -56: CALL(-56); break;       \
+    case -82: CALL(-82); break;       \
+    case -84: CALL(-84); break;       \
+    case -88: CALL(-88); break;       \
     default: CALL(0); break;          \
   }
 #ifdef USE_FLOAT

@@ -117,9 +117,9 @@ __global__ __launch_bounds__(256) void codes_kernel(QParams P, int Q, const FT *
       if (lane == 0) codes[(size_t)q * P.T + t] = code;
     }
   } else if constexpr (D < 0) {
-    constexpr int C = -D;
-    const int oc = P.d / (ANN_VEC * C), rpw = ANN_WAVE / oc;
-    const int g = lane / oc, p = lane - g * oc;
+    constexpr int C = OcCode<D>::C, OC = OcCode<D>::OC;
+    const OcLanes<D> ol(P.d, lane);
+    const int oc = ol.oc, rpw = ol.rpw, g = ol.g, p = ol.p;
     const long item = (long)blockIdx.x * wpb + w;
     const bool live = item < (long)Q * P.T;
     const int q = live ? (int)(item / P.T) : 0, t = live ? (int)(item % P.T) : 0;
@@ -137,12 +137,12 @@ __global__ __launch_bounds__(256) void codes_kernel(QParams P, int Q, const FT *
     u32 code = 0;
     for (int s0 = 0; s0 < P.ds; s0 += rpw) {
       const int sidx = s0 + g;
-      const bool act = g < rpw && sidx < P.ds;
+      const bool act = ol.valid && sidx < P.ds;
       const VT *bp = reinterpret_cast<const VT *>(P.bases + ((size_t)t * P.ds + (act ? sidx : 0)) * P.d) + p;
       VT b[C];
 #pragma unroll
       for (int c = 0; c < C; c++) b[c] = bp[c * oc];
-      FT v = row_reduce_oc<C, ROW_PRODUCT>(a, b, oc, p);
+      FT v = row_reduce_oc<C, ROW_PRODUCT, OC>(a, b, oc, p);
       u32 sign = (u32)(ft_bits(v) >> (sizeof(FT) * 8 - 1));
       if (act && p == 0 && sign) code |= 1u << (P.ds - 1 - sidx);
     }
@@ -316,13 +316,13 @@ __device__ __forceinline__ void gather_select(const QParams &P, const u32 *list,
       }
     }
   } else if constexpr (D < 0) {
-    constexpr int C = -D;
-    const int oc = P.d / (ANN_VEC * C), rpw = ANN_WAVE / oc;
-    const int g = lane / oc, p = lane - g * oc;  // lanes with g == rpw have no row
+    constexpr int C = OcCode<D>::C, OC = OcCode<D>::OC;
+    const OcLanes<D> ol(P.d, lane);
+    const int oc = ol.oc, rpw = ol.rpw, g = ol.g, p = ol.p;  // lanes with !ol.valid have no row
     VT bn[C];
     u32 idn = 0;
     if (cnt > 0) {
-      idn = list[(g < rpw && g < cnt) ? g : 0];
+      idn = list[(ol.valid && g < cnt) ? g : 0];
       const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(idn - P.lo) * P.d) + p;
 #pragma unroll
       for (int c = 0; c < C; c++) bn[c] = load_row_chunk<true>(rp + c * oc);
@@ -332,15 +332,15 @@ __device__ __forceinline__ void gather_select(const QParams &P, const u32 *list,
 #pragma unroll
       for (int c = 0; c < C; c++) b[c] = bn[c];
       const u32 id = idn;
-      const bool act = g < rpw && base + g < cnt && !(alias && id == x);
+      const bool act = ol.valid && base + g < cnt && !(alias && id == x);
       const int nb = base + rpw;
       if (nb < cnt) {
-        idn = list[(g < rpw && nb + g < cnt) ? nb + g : nb];
+        idn = list[(ol.valid && nb + g < cnt) ? nb + g : nb];
         const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(idn - P.lo) * P.d) + p;
 #pragma unroll
         for (int c = 0; c < C; c++) bn[c] = load_row_chunk<true>(rp + c * oc);
       }
-      const FT dist = row_reduce_oc<C, ROW_SQDIFF>(a, b, oc, p);
+      const FT dist = row_reduce_oc<C, ROW_SQDIFF, OC>(a, b, oc, p);
       const Key key = key_make(dist, id);
       const bool pass = act && p == 0 && key_less(key, S.tau);
       const u64 mm = __ballot(pass);
@@ -449,10 +449,10 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
 #pragma unroll
     for (int c = 0; c < L::C; c++) a[c] = yp[c * L::LPR];
   } else if constexpr (D < 0) {
-    const int oc = P.d / (ANN_VEC * -D);
-    const VT *yp = reinterpret_cast<const VT *>(y + (size_t)x * P.d) + (lane % oc);
+    const OcLanes<D> ol(P.d, lane);
+    const VT *yp = reinterpret_cast<const VT *>(y + (size_t)x * P.d) + ol.p;
 #pragma unroll
-    for (int c = 0; c < -D; c++) a[c] = yp[c * oc];
+    for (int c = 0; c < OcCode<D>::C; c++) a[c] = yp[c * ol.oc];
   }
 
   int cnt = 0;
@@ -686,18 +686,18 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
         if (act && p == 0) t_dist[t_slot[r]] = dist;
       }
     } else if constexpr (D < 0) {
-      constexpr int C = -D;
-      const int oc = P.d / (ANN_VEC * C), rpw = ANN_WAVE / oc;
-      const int g = lane / oc, p = lane - g * oc;
+      constexpr int C = OcCode<D>::C, OC = OcCode<D>::OC;
+      const OcLanes<D> ol(P.d, lane);
+      const int oc = ol.oc, rpw = ol.rpw, g = ol.g, p = ol.p;
       for (int base = w * rpw; base < cnt2; base += W * rpw) {
         const int r = base + g;
-        const bool act = g < rpw && r < cnt2;
+        const bool act = ol.valid && r < cnt2;
         const u32 id = t_gid[act ? r : base];
         const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(id - P.lo) * P.d) + p;
         VT b[C];
 #pragma unroll
         for (int c = 0; c < C; c++) b[c] = load_row_chunk<true>(rp + c * oc);
-        const FT dist = row_reduce_oc<C, ROW_SQDIFF>(a, b, oc, p);
+        const FT dist = row_reduce_oc<C, ROW_SQDIFF, OC>(a, b, oc, p);
         if (act && p == 0) t_dist[t_slot[r]] = dist;
       }
     } else {
@@ -953,10 +953,10 @@ __global__ __launch_bounds__(256) void row_dists_kernel(QParams P, int Q, const 
 #pragma unroll
     for (int c = 0; c < L::C; c++) a[c] = yp[c * L::LPR];
   } else if constexpr (D < 0) {
-    const int oc = P.d / (ANN_VEC * -D);
-    const VT *yp = reinterpret_cast<const VT *>(y + (size_t)x * P.d) + (lane % oc);
+    const OcLanes<D> ol(P.d, lane);
+    const VT *yp = reinterpret_cast<const VT *>(y + (size_t)x * P.d) + ol.p;
 #pragma unroll
-    for (int c = 0; c < -D; c++) a[c] = yp[c * oc];
+    for (int c = 0; c < OcCode<D>::C; c++) a[c] = yp[c * ol.oc];
   }
   u32 gathered = 0;
   // gridDim.y workgroups share one row: each takes every gridDim.y-th chunk of its slots
@@ -1014,18 +1014,18 @@ __global__ __launch_bounds__(256) void row_dists_kernel(QParams P, int Q, const 
         if (act && p == 0) dist_row[lslot[r]] = dist;
       }
     } else if constexpr (D < 0) {
-      constexpr int C = -D;
-      const int oc = P.d / (ANN_VEC * C), rpw = ANN_WAVE / oc;
-      const int g = lane / oc, p = lane - g * oc;
+      constexpr int C = OcCode<D>::C, OC = OcCode<D>::OC;
+      const OcLanes<D> ol(P.d, lane);
+      const int oc = ol.oc, rpw = ol.rpw, g = ol.g, p = ol.p;
       for (int base = w * rpw; base < cnt; base += W * rpw) {
         const int r = base + g;
-        const bool act = g < rpw && r < cnt;
+        const bool act = ol.valid && r < cnt;
         const u32 id = lid[act ? r : base];
         const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(id - P.lo) * P.d) + p;
         VT b[C];
 #pragma unroll
         for (int c = 0; c < C; c++) b[c] = load_row_chunk<true>(rp + c * oc);
-        const FT dist = row_reduce_oc<C, ROW_SQDIFF>(a, b, oc, p);
+        const FT dist = row_reduce_oc<C, ROW_SQDIFF, OC>(a, b, oc, p);
         if (act && p == 0) dist_row[lslot[r]] = dist;
       }
     } else {

@@ -120,28 +120,52 @@ def main():
     libc = ctypes.CDLL("libc.so.6")
     nbatches = args.warmup + args.steps
 
-    # ---- synthetic data + index (identical on every rank: same seed, deterministic build)
+    # ---- synthetic data + index (identical on every rank: same seed, deterministic build).  The libc random() stream
+    #      belongs to the workload (points -> precomp's rotations -> one draw per batch, time_results.c:94-103); the HIP
+    #      runtime draws from it too whenever it feels like it (observed at initialisation), so the stream is parked
+    #      while torch talks to the GPU -- the library does the same inside its own entry points.
+    class park_random:
+        def __enter__(self):
+            self.buf = ctypes.create_string_buffer(256)
+            libc.initstate.restype = ctypes.c_void_p
+            self.old = libc.initstate(ctypes.c_uint(1), self.buf, ctypes.c_size_t(256))
+
+        def __exit__(self, *exc):
+            libc.setstate.argtypes = [ctypes.c_void_p]
+            libc.setstate(self.old)
+
+    with park_random():
+        torch.zeros(1, device=device)           # the runtime is fully up before the stream is seeded
+        torch.cuda.synchronize()
     libc.srandom(args.seed)
     host_pts = None
     t0 = time.time()
     if args.data == "randnorm":
         host_pts = A.synth_randnorm(n * d, args.dtype, reset=True).reshape(n, d)   # time_results.c:94
-        points = torch.from_numpy(host_pts).to(device)
+        with park_random():
+            points = torch.from_numpy(host_pts).to(device)
+            torch.cuda.synchronize()
     else:
-        gen = torch.Generator(device=device)
-        gen.manual_seed(args.seed)
-        points = torch.randn((n, d), device=device, dtype=tdt, generator=gen)
-    torch.cuda.synchronize()
+        with park_random():
+            gen = torch.Generator(device=device)
+            gen.manual_seed(args.seed)
+            points = torch.randn((n, d), device=device, dtype=tdt, generator=gen)
+            torch.cuda.synchronize()
     datagen_s = time.time() - t0
     t0 = time.time()
     ix = A.Index.precomp(points, k, T)          # draws its rotations from the same random() stream (Q12)
-    torch.cuda.synchronize()
-    precomp_s = time.time() - t0
-    ix.set_stream(torch.cuda.current_stream().cuda_stream)
+    with park_random():
+        torch.cuda.synchronize()
+        precomp_s = time.time() - t0
+        ix.set_stream(torch.cuda.current_stream().cuda_stream)
     if args.data == "randnorm":                 # one genRand per batch, in order (time_results.c:103)
-        batches = [torch.from_numpy(A.synth_randnorm(Q * d, args.dtype).reshape(Q, d)).to(device) for _ in range(nbatches)]
+        host_batches = [A.synth_randnorm(Q * d, args.dtype).reshape(Q, d) for _ in range(nbatches)]
+        with park_random():
+            batches = [torch.from_numpy(b).to(device) for b in host_batches]
+        del host_batches
     else:
-        batches = [torch.randn((Q, d), device=device, dtype=tdt, generator=gen) for _ in range(nbatches)]
+        with park_random():
+            batches = [torch.randn((Q, d), device=device, dtype=tdt, generator=gen) for _ in range(nbatches)]
 
     runner = None
     if sharded:
