@@ -65,6 +65,7 @@ struct EnvCfg {
   bool exact = false, slot_scan = false, point_precomp = false, all_tries = false;
   int fuse = -1;      // ANN_HIP_FUSE: -1 unset, 0 never, 1 whenever possible
   int s1_waves = 0;   // ANN_HIP_S1_WAVES: 0 unset
+  int tail = -1;      // ANN_HIP_TAIL: 0 = stage 2 as separate rows / network / widen kernels (the classic path, A/B and tests)
   int segx = -1;      // ANN_HIP_SEGX: -1 unset (auto: shards of <= 30 % of the rows), 0 never, 1 whenever the shard qualifies
   size_t lds_row_max = 150 * 1024, exact_bytes = (size_t)1 << 30;
   size_t exact_rows = 0;  // ANN_HIP_EXACT_ROWS: rows of the device-driven exact workspace (0 = auto)
@@ -90,6 +91,7 @@ static void load_env() {
   c.s1_waves = env_int("ANN_HIP_S1_WAVES", 0);
   if (c.s1_waves < 1 || c.s1_waves > 4) c.s1_waves = 0;
   c.segx = env_int("ANN_HIP_SEGX", -1);
+  c.tail = env_int("ANN_HIP_TAIL", -1);
   c.lds_row_max = env_size("ANN_HIP_LDS_ROW_MAX", 150 * 1024);
   c.exact_bytes = env_size("ANN_HIP_EXACT_BYTES", (size_t)1 << 30);
   c.exact_rows = env_size("ANN_HIP_EXACT_ROWS", 0);
@@ -459,7 +461,9 @@ static int layout_code(size_t d, bool allow_oc = true) {
     size_t nc = d / ANN_VEC, C = 1;
     while (C < 8 && nc % (2 * C) == 0) C *= 2;
     const size_t oc = nc / C;
+#ifndef ANN_NO_STATIC_OC
     if ((oc == 3 || oc == 5) && C >= 2) return -(int)(16 * oc + C);  // static layout, DPP-only tail (d = 80: oc = 5)
+#endif
     if (oc >= 2 && oc <= 64) return -(int)C;
   }
   return 0;
@@ -873,8 +877,31 @@ static long query_impl(annhip_index *ix, annhip_workspace &ws, hipStream_t s, si
                                      ws.flist, ws.xids, ws.xd, ws.d_fcount, rows_ctr, ix->d_rows + 2, true, s);
   seg_mark(ix, marks, s);
   // stage 2 (det_results second half, alg.c:314-327)
-  u32 *out_i = (u32 *)ws.out_i.need(sizeof(u32) * Q * k);
   FT *out_d = dists_dev ? reinterpret_cast<FT *>(dists_dev) : (FT *)ws.out_d.need(sizeof(FT) * Q * k);
+  if (ix->lo == 0 && ix->hi == ix->n && P.Lc2 <= 1024 && env().tail != 0) {
+    // one kernel: row assembly, neighbour gathers, network and size_t ids per query (stage2_fused_kernel)
+    size_t smem = sizeof(Key) * (size_t)k + 3 * sizeof(u32) * (size_t)P.Lc2 + 16;
+    smem = (smem + 15) & ~(size_t)15;
+    smem += sizeof(FT) * (size_t)P.Lc2;
+    smem = (smem + 15) & ~(size_t)15;
+    if (d_needs_lds_row(P.d)) smem += sizeof(FT) * (size_t)P.d * 3;
+#define CALL(DD)                                                                                               \
+  do {                                                                                                         \
+    allow_lds(stage2_fused_kernel<DD>, smem);                                                                  \
+    hipLaunchKernelGGL(stage2_fused_kernel<DD>, dim3((unsigned)Q), dim3(128), smem, s, P, (int)Q, y, alias, top_i, \
+                       top_d, P.Lc2, ids_dev, out_d, rows_ctr);                                                \
+  } while (0)
+    ANN_DISPATCH_D(P.d, CALL);
+#undef CALL
+    HIPCHECK(hipGetLastError());
+    seg_mark(ix, marks, s);  // "stage2_rows" = the whole fused stage 2; "stage2_network" and "widen" stay 0
+    seg_mark(ix, marks, s);
+    seg_mark(ix, marks, s);
+    if (marks) ix->seg_used.push_back(marks_store);
+    ix->queries += (double)Q;
+    return nflag;
+  }
+  u32 *out_i = (u32 *)ws.out_i.need(sizeof(u32) * Q * k);
   const size_t row_bytes = (size_t)P.Lc2 * (sizeof(FT) + sizeof(u32));
   size_t chunk = ((size_t)2 << 30) / row_bytes;
   if (chunk < 1) chunk = 1;
@@ -1275,8 +1302,15 @@ static HostGivens draw_givens(size_t rots, size_t len, size_t dim) {
       g.ci.push_back(sel[2 * i]);
       g.cj.push_back(sel[2 * i + 1]);
       FT ang = (FT)(unit_draw() * M_PI);
-      g.c.push_back((FT)cos((double)ang));
-      g.s.push_back((FT)sin((double)ang));
+      // The reference's CPU path computes `s = sincos(ang, &c)` = (c = cos(a), sin(a)) (ocl2c.h:10, compute.cl:63), which
+      // gcc -O2 -- its build and the oracle's -- fuses into ONE glibc sincos() call; that call differs from cos()/sin()
+      // in the last bit for ~0.1 % of the arguments.  Invisible after rounding to float, but in the double build it
+      // showed as 1-ulp differences in `bases` for ~7 % of the seeds: call sincos() so that the index is the reference
+      // binary's bit for bit.
+      double sn, cs;
+      sincos((double)ang, &sn, &cs);
+      g.c.push_back((FT)cs);
+      g.s.push_back((FT)sn);
     }
   }
   return g;

@@ -366,6 +366,127 @@ __device__ __forceinline__ void gather_select(const QParams &P, const u32 *list,
   wave_lds_sync();
 }
 
+// Stage 2 of ONE query on the calling workgroup (det_results second half, alg.c:314-327): row of len2 entries =
+// the stage-1 top-k (`top`, LDS, ascending keys) followed by the graph neighbours of each of them (supercharge,
+// compute.cl:252-263); distances of the new slots gathered here (owned, valid, not the excluded self: else +inf);
+// the reference's network + rdups + network in LDS (alg.c:224-230); first k entries to out_ids/out_dist[x].
+// t_* and cnt2p are LDS scratch (len2 entries each; *cnt2p must be 0 on entry).  Returns the rows gathered.
+template <int D>
+__device__ __forceinline__ u32 stage2_in_workgroup(const QParams &P, u32 x, int alias, const VT (&a)[RowChunks<D>::C],
+                                                   const FT *yq, FT *scratch, const Key *top, int k, u32 len2,
+                                                   u32 *t_ids, u32 *t_slot, u32 *t_gid, FT *t_dist, u32 *cnt2p,
+                                                   size_t *__restrict__ out_ids, FT *__restrict__ out_dist) {
+  const int lane = lane_id(), w = threadIdx.x >> 6, W = blockDim.x >> 6;
+  for (u32 j = threadIdx.x; j < len2; j += blockDim.x) {
+    u32 id;
+    if (j < (u32)k) {
+      id = key_id(top[j]);
+      t_dist[j] = key_dist(top[j]);
+    } else {
+      const u32 parent = key_id(top[j / k - 1]), z = j % k;
+      id = parent < P.n ? P.graph[(size_t)parent * k + z] : (P.graph[z] | P.n);  // supercharge, Q7
+      const bool ok = id < P.n && !(alias && id == x) && id >= P.lo && id < P.hi;
+      if (ok) {
+        const u32 pos = atomicAdd(cnt2p, 1u);
+        t_slot[pos] = j;
+        t_gid[pos] = id;
+      } else {
+        t_dist[j] = ft_inf();
+      }
+    }
+    t_ids[j] = id;
+  }
+  __syncthreads();
+  const int cnt2 = (int)*cnt2p;
+  if constexpr (D > 0) {
+    typedef RowLay<D> L;
+    const int p = lane % L::LPR, g = lane / L::LPR;
+    for (int base = w * L::RPW; base < cnt2; base += W * L::RPW) {
+      const int r = base + g;
+      const bool act = r < cnt2;
+      const u32 id = t_gid[act ? r : base];
+      const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(id - P.lo) * D) + p;
+      VT b[L::C];
+#pragma unroll
+      for (int c = 0; c < L::C; c++) b[c] = load_row_chunk<true>(rp + c * L::LPR);
+      const FT dist = row_reduce<D, ROW_SQDIFF>(a, b);
+      if (act && p == 0) t_dist[t_slot[r]] = dist;
+    }
+  } else if constexpr (D < 0) {
+    constexpr int C = OcCode<D>::C, OC = OcCode<D>::OC;
+    const OcLanes<D> ol(P.d, lane);
+    const int oc = ol.oc, rpw = ol.rpw, g = ol.g, p = ol.p;
+    for (int base = w * rpw; base < cnt2; base += W * rpw) {
+      const int r = base + g;
+      const bool act = ol.valid && r < cnt2;
+      const u32 id = t_gid[act ? r : base];
+      const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(id - P.lo) * P.d) + p;
+      VT b[C];
+#pragma unroll
+      for (int c = 0; c < C; c++) b[c] = load_row_chunk<true>(rp + c * oc);
+      const FT dist = row_reduce_oc<C, ROW_SQDIFF, OC>(a, b, oc, p);
+      if (act && p == 0) t_dist[t_slot[r]] = dist;
+    }
+  } else {
+    for (int r = w; r < cnt2; r += W) {
+      const FT dist = row_reduce_generic<ROW_SQDIFF>(P.d, yq, P.points + (size_t)(t_gid[r] - P.lo) * P.d, scratch);
+      if (lane == 0) t_dist[t_slot[r]] = dist;
+    }
+  }
+  __syncthreads();
+  block_topk_stage<true>((size_t)k * (k + 1), len2, t_dist, t_ids);  // sort_and_uniq, alg.c:327
+  for (int t = threadIdx.x; t < k; t += blockDim.x) {
+    out_ids[(size_t)x * k + t] = t_ids[t];
+    out_dist[(size_t)x * k + t] = t_dist[t];
+  }
+  return (u32)cnt2;
+}
+
+// Stage 2 as ONE kernel (single-device query path, stage-2 rows that fit LDS): per query the row assembly, the <= k*k
+// neighbour gathers, the network and the size_t ids -- what row_dists<GRAPH> + exact_select + widen_ids did with three
+// launches and two round trips of the [Q][Lc2] rows through HBM (cfg3: 58 + 33 + 6 us -> one ~60 us kernel).
+template <int D>
+__global__ __launch_bounds__(128) void stage2_fused_kernel(QParams P, int Q, const FT *__restrict__ y, int alias,
+                                                           const u32 *__restrict__ top_id, const FT *__restrict__ top_dist,
+                                                           u32 len2, size_t *__restrict__ out_ids,
+                                                           FT *__restrict__ out_dist,
+                                                           unsigned long long *__restrict__ rows_done) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = lane_id(), w = threadIdx.x >> 6;
+  const u32 x = blockIdx.x;
+  const int k = P.k;
+  unsigned char *sp = smem;
+  Key *top = reinterpret_cast<Key *>(sp);     sp += sizeof(Key) * (size_t)k;
+  u32 *t_ids = reinterpret_cast<u32 *>(sp);   sp += sizeof(u32) * (size_t)len2;
+  u32 *t_slot = reinterpret_cast<u32 *>(sp);  sp += sizeof(u32) * (size_t)len2;
+  u32 *t_gid = reinterpret_cast<u32 *>(sp);   sp += sizeof(u32) * (size_t)len2;
+  u32 *cnt2 = reinterpret_cast<u32 *>(sp);    sp += sizeof(u32) * 4;
+  sp = smem + (((sp - smem) + 15) & ~(size_t)15);
+  FT *t_dist = reinterpret_cast<FT *>(sp);    sp += sizeof(FT) * (size_t)len2;
+  sp = smem + (((sp - smem) + 15) & ~(size_t)15);
+  FT *yq = reinterpret_cast<FT *>(sp);  // generic d only: [d] + 2*[d]
+  for (int t = threadIdx.x; t < k; t += blockDim.x) top[t] = key_make(top_dist[(size_t)x * k + t], top_id[(size_t)x * k + t]);
+  if (threadIdx.x == 0) *cnt2 = 0;
+  if constexpr (D == 0)
+    for (int z = threadIdx.x; z < P.d; z += blockDim.x) yq[z] = y[(size_t)x * P.d + z];
+  VT a[RowChunks<D>::C];
+  if constexpr (D > 0) {
+    typedef RowLay<D> L;
+    const VT *yp = reinterpret_cast<const VT *>(y + (size_t)x * D) + (lane % L::LPR);
+#pragma unroll
+    for (int c = 0; c < L::C; c++) a[c] = yp[c * L::LPR];
+  } else if constexpr (D < 0) {
+    const OcLanes<D> ol(P.d, lane);
+    const VT *yp = reinterpret_cast<const VT *>(y + (size_t)x * P.d) + ol.p;
+#pragma unroll
+    for (int c = 0; c < OcCode<D>::C; c++) a[c] = yp[c * ol.oc];
+  }
+  __syncthreads();
+  const u32 got = stage2_in_workgroup<D>(P, x, alias, a, yq, yq + (size_t)(1 + w) * P.d, top, k, len2, t_ids, t_slot, t_gid,
+                                         t_dist, cnt2, out_ids, out_dist);
+  if (rows_done && threadIdx.x == 0) atomicAdd(&rows_done[(x & 63u) * 8u], (unsigned long long)got);
+}
+
 // One workgroup per query; its waves split the work on the first P1 slots of the candidate row.  Per wave:
 //   A) SEG: for its share of the (try, hamming-neighbour) runs below P1, read the bucket's segment word and copy
 //      the owned ids into an LDS list (prefix sum over the lanes' counts, then a balanced copy);
@@ -648,71 +769,9 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
   }
   // ---- fused stage 2 (det_results second half, alg.c:314-327) on this query's own workgroup
   {
-    const int k = K1 - 1;
-    const Key *top = kout_all;  // wave 0's sorted survivors: the stage-1 top-k
-    for (u32 j = threadIdx.x; j < F.len2; j += blockDim.x) {
-      u32 id;
-      if (j < (u32)k) {
-        id = key_id(top[j]);
-        t_dist[j] = key_dist(top[j]);
-      } else {
-        const u32 parent = key_id(top[j / k - 1]), z = j % k;
-        id = parent < P.n ? P.graph[(size_t)parent * k + z] : (P.graph[z] | P.n);  // supercharge, Q7
-        const bool ok = id < P.n && !(alias && id == x) && id >= P.lo && id < P.hi;
-        if (ok) {
-          const u32 pos = atomicAdd(&cnts[2], 1u);
-          t_slot[pos] = j;
-          t_gid[pos] = id;
-        } else {
-          t_dist[j] = ft_inf();
-        }
-      }
-      t_ids[j] = id;
-    }
-    __syncthreads();
-    const int cnt2 = (int)cnts[2];
-    if constexpr (D > 0) {
-      typedef RowLay<D> L;
-      const int p = lane % L::LPR, g = lane / L::LPR;
-      for (int base = w * L::RPW; base < cnt2; base += W * L::RPW) {
-        const int r = base + g;
-        const bool act = r < cnt2;
-        const u32 id = t_gid[act ? r : base];
-        const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(id - P.lo) * D) + p;
-        VT b[L::C];
-#pragma unroll
-        for (int c = 0; c < L::C; c++) b[c] = load_row_chunk<true>(rp + c * L::LPR);
-        const FT dist = row_reduce<D, ROW_SQDIFF>(a, b);
-        if (act && p == 0) t_dist[t_slot[r]] = dist;
-      }
-    } else if constexpr (D < 0) {
-      constexpr int C = OcCode<D>::C, OC = OcCode<D>::OC;
-      const OcLanes<D> ol(P.d, lane);
-      const int oc = ol.oc, rpw = ol.rpw, g = ol.g, p = ol.p;
-      for (int base = w * rpw; base < cnt2; base += W * rpw) {
-        const int r = base + g;
-        const bool act = ol.valid && r < cnt2;
-        const u32 id = t_gid[act ? r : base];
-        const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(id - P.lo) * P.d) + p;
-        VT b[C];
-#pragma unroll
-        for (int c = 0; c < C; c++) b[c] = load_row_chunk<true>(rp + c * oc);
-        const FT dist = row_reduce_oc<C, ROW_SQDIFF, OC>(a, b, oc, p);
-        if (act && p == 0) t_dist[t_slot[r]] = dist;
-      }
-    } else {
-      for (int r = w; r < cnt2; r += W) {
-        const FT dist = row_reduce_generic<ROW_SQDIFF>(P.d, yq, P.points + (size_t)(t_gid[r] - P.lo) * P.d, scratch);
-        if (lane == 0) t_dist[t_slot[r]] = dist;
-      }
-    }
-    __syncthreads();
-    block_topk_stage<true>((size_t)k * (k + 1), F.len2, t_dist, t_ids);  // sort_and_uniq, alg.c:327
-    for (int t = threadIdx.x; t < k; t += blockDim.x) {
-      F.out_ids[(size_t)x * k + t] = t_ids[t];
-      F.out_dist[(size_t)x * k + t] = t_dist[t];
-    }
-    if (threadIdx.x == 0) nv_own[x] = cnts[1] + (u32)cnt2;  // rows gathered for this query, both stages
+    const u32 cnt2 = stage2_in_workgroup<D>(P, x, alias, a, yq, scratch, kout_all /* wave 0's sorted survivors */, K1 - 1,
+                                            F.len2, t_ids, t_slot, t_gid, t_dist, &cnts[2], F.out_ids, F.out_dist);
+    if (threadIdx.x == 0) nv_own[x] = cnts[1] + cnt2;  // rows gathered for this query, both stages
   }
   }  // FUSED
 }

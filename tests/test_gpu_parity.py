@@ -21,20 +21,24 @@ def _check(ids, dists, g_ids, g_dists, what):
     assert bits_equal(dists, g_dists), "%s: distances not bit-identical" % what
 
 
-@pytest.fixture(params=["select", "select-unfused", "exact"])
+@pytest.fixture(params=["select", "select-unfused", "select-classic", "exact"])
 def path_mode(request):
-    """'select' = production path (selection + exact fallback; small batches take the fused stage-2 tail);
-    'select-unfused' = the same with the separate stage-2 kernels; 'exact' = the reference network for every row."""
-    os.environ.pop("ANN_HIP_EXACT", None)
-    os.environ.pop("ANN_HIP_FUSE", None)
+    """'select' = production path (selection + exact fallback; small batches run stage 2 in the tail of the stage-1
+    workgroup); 'select-unfused' = stage 2 as its own fused kernel (what large batches take); 'select-classic' = stage 2
+    as separate rows / network / widen kernels (what sharded indexes and long stage-2 rows take); 'exact' = the
+    reference network for every row."""
+    for v in ("ANN_HIP_EXACT", "ANN_HIP_FUSE", "ANN_HIP_TAIL"):
+        os.environ.pop(v, None)
     if request.param == "exact":
         os.environ["ANN_HIP_EXACT"] = "1"
     elif request.param == "select-unfused":
         os.environ["ANN_HIP_FUSE"] = "0"
+    elif request.param == "select-classic":
+        os.environ["ANN_HIP_FUSE"], os.environ["ANN_HIP_TAIL"] = "0", "0"
     A._lib.reload_env()
     yield request.param
-    os.environ.pop("ANN_HIP_EXACT", None)
-    os.environ.pop("ANN_HIP_FUSE", None)
+    for v in ("ANN_HIP_EXACT", "ANN_HIP_FUSE", "ANN_HIP_TAIL"):
+        os.environ.pop(v, None)
     A._lib.reload_env()
 
 

@@ -8,4 +8,8 @@ name=$1; shift
 mkdir -p ab/$name
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Wall -Wno-unused-function -pthread \
     -DUSE_FLOAT "$@" -o ab/$name/libapproxnn_hip_f32.so ann_host.hip ann_saveio.cpp ann_synth.cpp
+if [ -n "$AB_F64" ]; then  # AB_F64=1: the double build too
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Wall -Wno-unused-function -pthread \
+      "$@" -o ab/$name/libapproxnn_hip_f64.so ann_host.hip ann_saveio.cpp ann_synth.cpp
+fi
 echo "built ab/$name"
