@@ -70,6 +70,16 @@ def load(prec="f32"):
     lib.annhip_save_read.argtypes = [C.c_char_p, C.POINTER(SaveT)]
     lib.annhip_precomp_index.restype = vp
     lib.annhip_precomp_index.argtypes = [sz, sz, sz, vp, C.c_int, C.c_int, sz, sz, sz, sz, vp]
+    lib.annhip_precomp_begin.restype = vp
+    lib.annhip_precomp_begin.argtypes = [sz, sz, sz, vp, C.c_int, C.c_int, sz, sz, sz, sz, C.c_int, C.c_int]
+    lib.annhip_precomp_info.argtypes = [vp, C.POINTER(sz * 6)]
+    lib.annhip_precomp_init_merged.argtypes = [vp, u32p, vp]
+    lib.annhip_precomp_hash.argtypes = [vp, C.c_int, sz, sz, u32p]
+    lib.annhip_precomp_try.argtypes = [vp, C.c_int, u32p, u32p, vp]
+    lib.annhip_precomp_merge.argtypes = [vp, u32p, vp]
+    lib.annhip_precomp_graph.argtypes = [vp, sz, sz, u32p, vp]
+    lib.annhip_precomp_finish.restype = vp
+    lib.annhip_precomp_finish.argtypes = [vp, u32p]
     lib.annhip_query.restype = C.c_long
     lib.annhip_query.argtypes = [vp, sz, vp, C.c_int, C.c_int, vp, vp]
     lib.annhip_workspace_create.restype = vp
@@ -127,7 +137,8 @@ def load(prec="f32"):
 # every symbol include/*.h declares for the backend library (checked by tests/test_abi.py)
 EXPORTED = ["gpu_init", "gpu_cleanup", "register_cleanup", "query_gpu", "precomp_gpu", "annhip_precision",
             "annhip_index_create", "annhip_index_destroy", "annhip_index_info", "annhip_index_set_stream",
-            "annhip_index_export", "annhip_index_reshard", "annhip_save_write", "annhip_save_read", "annhip_precomp_index", "annhip_query", "annhip_workspace_create", "annhip_workspace_destroy", "annhip_query_on", "annhip_stream_open", "annhip_stream_submit", "annhip_stream_collect", "annhip_stream_close",
+            "annhip_index_export", "annhip_index_reshard", "annhip_save_write", "annhip_save_read", "annhip_precomp_index", "annhip_precomp_begin", "annhip_precomp_info", "annhip_precomp_init_merged", "annhip_precomp_hash",
+            "annhip_precomp_try", "annhip_precomp_merge", "annhip_precomp_graph", "annhip_precomp_finish", "annhip_query", "annhip_workspace_create", "annhip_workspace_destroy", "annhip_query_on", "annhip_stream_open", "annhip_stream_submit", "annhip_stream_collect", "annhip_stream_close",
             "annhip_key_bytes", "annhip_stream_create_reserving", "annhip_stream_destroy", "annhip_sh_codes", "annhip_sh_stage1", "annhip_sh_merge_finalize", "annhip_sh_exact1_begin", "annhip_sh_exact1_end", "annhip_sh_stage2",
             "annhip_sh_final", "annhip_stage1_rows", "annhip_stage2_rows_list", "annhip_exact_select",
             "annhip_recall_ranks", "annhip_profile", "annhip_stats", "annhip_stage_ms",

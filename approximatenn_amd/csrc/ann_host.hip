@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <limits>
 #include <mutex>
 #include <vector>
 
@@ -257,6 +258,7 @@ static QParams make_params(const annhip_index *ix) {
   return P;
 }
 
+static FT ft_inf_host() { return std::numeric_limits<FT>::infinity(); }
 static u32 magic_for(u32 pm) { return (u32)((1ull << 32) / pm) + 1u; }
 
 // derive row geometry (SURVEY 8 notation) once the tries are known
@@ -639,17 +641,17 @@ static void launch_stage1(annhip_index *ix, const QParams &P, size_t Q, const FT
 
 template <int DD>
 static void launch_bucket_d(const QParams &P, size_t nbuckets, int W, int K1, u32 list_cap, size_t smem, FT *cand_d,
-                            u32 *cand_i, u32 *nvt, u32 *nvo, hipStream_t s) {
+                            u32 *cand_i, u32 *nvt, u32 *nvo, hipStream_t s, u32 brem, u32 bmod) {
   if constexpr (DD > 0) {
     allow_lds(stage1_bucket_kernel<DD>, smem);
     hipLaunchKernelGGL(stage1_bucket_kernel<DD>, dim3((unsigned)nbuckets), dim3(64 * W), smem, s, P, K1, list_cap, cand_d,
-                       cand_i, nvt, nvo);
+                       cand_i, nvt, nvo, brem, bmod);
   }
 }
 
 // bucket-centric stage 1 of precomp: returns false when the shape does not fit (caller uses the per-point kernel)
 static bool launch_stage1_bucket(const QParams &P, const TryInfo &one, size_t nbuckets, FT *cand_d, u32 *cand_i, u32 *nvt,
-                                 u32 *nvo, hipStream_t s) {
+                                 u32 *nvo, hipStream_t s, u32 brem = 0, u32 bmod = 1) {
   if (!d_is_fast(P.d) || env().point_precomp) return false;
   const int K1 = P.k + 1, W = ANN_BK_WAVES;
   if (K1 > ANN_WAVE) return false;  // the wave-resident selection holds one key per lane
@@ -661,7 +663,7 @@ static bool launch_stage1_bucket(const QParams &P, const TryInfo &one, size_t nb
                       sizeof(u32) * (ANN_BK_MAX_RUNS + 1) + 16;
   if (smem > 80 * 1024) return false;  // keep two workgroups per CU
   if ((u32)P.k > P.P1) return false;
-#define CALL(DD) launch_bucket_d<DD>(P, nbuckets, W, K1, list_cap, smem, cand_d, cand_i, nvt, nvo, s)
+#define CALL(DD) launch_bucket_d<DD>(P, nbuckets, W, K1, list_cap, smem, cand_d, cand_i, nvt, nvo, s, brem, bmod)
   ANN_DISPATCH_D2(P.d, CALL);
 #undef CALL
   HIPCHECK(hipGetLastError());
@@ -1328,34 +1330,65 @@ static T *upload_vec(const std::vector<T> &v, std::vector<void *> &owned) {
   return p;
 }
 
-extern "C" annhip_index *annhip_precomp_index(size_t n, size_t k, size_t d, const ftype *points, int on_device,
-                                              int tries, size_t rots_before, size_t rot_len_before,
-                                              size_t rots_after, size_t rot_len_after, ftype *graph_dists_dev) {
+// precomp() in phases (alg.c:342-434).  A single device runs them back to back (annhip_precomp_index); a sharded host
+// (one process per GPU, every rank holding ALL n rows during the build) puts three collectives between them:
+//   begin                      draws (Q12), means, centring                                   -- every rank, identical
+//   per try:  hash(rows)       run_initial on this rank's row slice           -> ALL-GATHER of the codes (4 B / point)
+//             try              bucket table (all ranks), then second_half's distance pass for THIS RANK'S BUCKETS
+//                              (bucket b belongs to rank b mod G) into its members' columns of merged_i / merged_d
+//   after the tries                                                          -> MIN ALL-REDUCE of merged_i, merged_d
+//                              (entries nobody computed hold INT32_MAX / +inf; every entry has one writer)
+//   merge                      det_results' first network over the merged rows -- every rank, all rows (17 ms at cfg3)
+//   graph(rows)                supercharge + distances + network for this rank's rows -> ALL-GATHER of the graph rows
+//   finish                     the resident index
+struct annhip_precomp {
+  size_t n = 0, k = 0, d = 0, ds = 0, d_max = 0, nb = 0, W = 0, need_W = 0, Wn = 0;
+  int T = 0, tries_scored = 0, rank = 0, world = 1;
+  size_t rots_before = 0, rot_len_before = 0, rots_after = 0, rot_len_after = 0;
+  std::vector<HostXform> hx;
+  annhip_index *ix = NULL;
+  FT *centred = NULL;
+  u32 *cnt = NULL, *cursor = NULL, *d_max_cnt = NULL, *d_bad = NULL, *top_i = NULL;
+  FT *top_d = NULL;
+  TryInfo *solo = NULL;
+  DevBuf cand_d, cand_i, nvt, nvo, flist, xids, xd;
+  bool exact_all = false;
+  hipStream_t s = 0;
+};
+
+extern "C" annhip_precomp *annhip_precomp_begin(size_t n, size_t k, size_t d, const ftype *points, int on_device, int tries,
+                                                size_t rots_before, size_t rot_len_before, size_t rots_after,
+                                                size_t rot_len_after, int rank, int world) {
   if (n <= k || k < 1) die("need n > k >= 1");
+  if (world < 1 || rank < 0 || rank >= world) die("annhip_precomp_begin: bad rank/world");
   // alg.c:347-357 (Q13: evaluated in ftype)
   size_t ds = (size_t)ceil(log2((FT)n / k));
   size_t d_max = 1;
   while (d_max < d) d_max <<= 1;
   if (ds > d_max) ds = d_max;
   check_limits(n, k, d, ds, tries);
+  if (world > 1 && n >= (1ull << 30)) die("sharded precomp exchanges ids as 32-bit signed values: n < 2^30");
   if ((rots_before && 2 * rot_len_before > d) || (rots_after && 2 * rot_len_after > ds))
     die("rotation length exceeds dimension (rand_rot needs 2*len <= dim; the reference divides by zero there)");
+  annhip_precomp *h = new annhip_precomp();
   const int T = tries;
+  h->n = n, h->k = k, h->d = d, h->ds = ds, h->d_max = d_max, h->T = T, h->rank = rank, h->world = world;
+  h->rots_before = rots_before, h->rot_len_before = rot_len_before, h->rots_after = rots_after, h->rot_len_after = rot_len_after;
   // Every transform is drawn up front, in the reference's order (alg.c:387-392, Q12), and BEFORE any HIP call:
   // these draws are the only use this path makes of the caller's random() stream.
-  std::vector<HostXform> hx(T);
+  h->hx.resize(T);
   for (int t = 0; t < T; t++) {
-    hx[t].before = draw_givens(rots_before, rot_len_before, d);
-    hx[t].after = draw_givens(rots_after, rot_len_after, ds);
-    hx[t].perm_b = draw_perm(d, d_max);
-    hx[t].perm_ai = draw_perm(ds, d_max);
+    h->hx[t].before = draw_givens(rots_before, rot_len_before, d);
+    h->hx[t].after = draw_givens(rots_after, rot_len_after, ds);
+    h->hx[t].perm_b = draw_perm(d, d_max);
+    h->hx[t].perm_ai = draw_perm(ds, d_max);
   }
   RandGuard keep_callers_stream;
   gpu_init();
-  const bool exact_all = env().exact;
-  hipStream_t s = 0;
+  h->exact_all = env().exact;
+  hipStream_t s = h->s;
 
-  annhip_index *ix = new annhip_index();
+  annhip_index *ix = h->ix = new annhip_index();
   ix->n = n, ix->k = k, ix->d = d, ix->ds = ds, ix->T = T, ix->lo = 0, ix->hi = n;
   if (on_device) {
     ix->d_points = const_cast<FT *>(reinterpret_cast<const FT *>(points));
@@ -1368,174 +1401,257 @@ extern "C" annhip_index *annhip_precomp_index(size_t n, size_t k, size_t d, cons
 
   // column means + centring (alg.c:360-369)
   ix->d_means = dev_alloc<FT>(d);
-  FT *centred = dev_alloc<FT>(n * d);
+  h->centred = dev_alloc<FT>(n * d);
   {
     FT *acc = dev_alloc<FT>((n / 2) * d);
     rows_add0_kernel<<<grid_for((n / 2) * d, 256, 8192), 256, 0, s>>>(n, d, pts, acc);
     for (size_t m = n >> 1; m >> 1; m >>= 1)
       rows_addn_kernel<<<grid_for((m / 2) * d, 256, 8192), 256, 0, s>>>(m, d, acc);
     means_finish_kernel<<<grid_for(d, 256), 256, 0, s>>>(n, d, acc, ix->d_means);
-    centre_kernel<<<grid_for(n * d, 256, 16384), 256, 0, s>>>(n, d, pts, ix->d_means, centred);
+    centre_kernel<<<grid_for(n * d, 256, 16384), 256, 0, s>>>(n, d, pts, ix->d_means, h->centred);
     HIPCHECK(hipStreamSynchronize(s));
     HIPCHECK(hipFree(acc));
   }
-
-  // hash codes per try (run_initial) and the projection rows (save_vecs)
   ix->d_bases = dev_alloc<FT>((size_t)T * ds * d);
-  std::vector<u32 *> codes(T);
-  std::vector<void *> owned;
-  for (int t = 0; t < T; t++) {
-    XformDev X;
-    X.b_i = upload_vec(hx[t].before.ci, owned), X.b_j = upload_vec(hx[t].before.cj, owned);
-    X.b_c = upload_vec(hx[t].before.c, owned), X.b_s = upload_vec(hx[t].before.s, owned);
-    X.a_i = upload_vec(hx[t].after.ci, owned), X.a_j = upload_vec(hx[t].after.cj, owned);
-    X.a_c = upload_vec(hx[t].after.c, owned), X.a_s = upload_vec(hx[t].after.s, owned);
-    X.perm_b = upload_vec(hx[t].perm_b, owned), X.perm_ai = upload_vec(hx[t].perm_ai, owned);
-    X.rots_b = (int)rots_before, X.rlb = (int)rot_len_before, X.rots_a = (int)rots_after, X.rla = (int)rot_len_after;
-    X.d = (int)d, X.d_max = (int)d_max, X.ds = (int)ds, X.l = ann_lg(d_max);
-    codes[t] = dev_alloc<u32>(n);
-    const int wpb = 4;
-    size_t smem = sizeof(FT) * wpb * (d + d_max + ds);
-    allow_lds(hash_rows_kernel, smem);
-    hipLaunchKernelGGL(hash_rows_kernel, dim3((unsigned)((n + wpb - 1) / wpb)), dim3(64 * wpb), smem, s, X, n, centred,
-                       codes[t]);
-    HIPCHECK(hipGetLastError());
-    if (ds) {
-      smem = sizeof(FT) * wpb * (d + d_max);
-      allow_lds(bases_rows_kernel, smem);
-      hipLaunchKernelGGL(bases_rows_kernel, dim3((unsigned)((ds + wpb - 1) / wpb)), dim3(64 * wpb), smem, s, X,
-                         ix->d_bases + (size_t)t * ds * d);
-      HIPCHECK(hipGetLastError());
-    }
-  }
-  HIPCHECK(hipStreamSynchronize(s));
-  for (void *p : owned) HIPCHECK(hipFree(p));
-  HIPCHECK(hipFree(centred));
 
-  // second_half per try (alg.c:245-290): bucket table, then each point's candidates -> its k best
   // The merge over tries (det_results, alg.c:308-312) sorts a row of W = k*T entries, i.e. only its first
   // ann_need_len(W, k) columns are ever read: a try whose column block starts at or beyond that length
   // contributes its bucket table (query() probes every table) but its distance pass would be computed and never
   // looked at -- tries 7..9 of 10 at cfg3, 6..9 at cfg5.  Those tries skip the pass, and the merged rows are stored
   // with the shorter stride Wn (cfg5: 61 GB instead of 120 GB).  ANN_HIP_PRECOMP_ALL_TRIES=1 runs every pass (A/B).
-  const size_t nb = (size_t)1 << ds, W = k * (size_t)T;
-  const size_t need_W = ann_need_len(W, k);
-  const int tries_scored = env().all_tries ? T : (int)std::min<size_t>((size_t)T, (need_W + k - 1) / k);
-  const size_t Wn = (size_t)tries_scored * k;
-  u32 *merged_i = dev_alloc<u32>(n * Wn);
-  FT *merged_d = dev_alloc<FT>(n * Wn);
-  u32 *cnt = dev_alloc<u32>(nb), *cursor = dev_alloc<u32>(nb), *d_max_cnt = dev_alloc<u32>(1);
+  h->nb = (size_t)1 << ds, h->W = k * (size_t)T;
+  h->need_W = ann_need_len(h->W, k);
+  h->tries_scored = env().all_tries ? T : (int)std::min<size_t>((size_t)T, (h->need_W + k - 1) / k);
+  h->Wn = (size_t)h->tries_scored * k;
+  h->cnt = dev_alloc<u32>(h->nb), h->cursor = dev_alloc<u32>(h->nb), h->d_max_cnt = dev_alloc<u32>(1);
   ix->h_tries.resize(T);
   ix->d_tabs.resize(T);
   ix->d_segs.assign(T, NULL);
-  u32 *d_bad = dev_alloc<u32>(1);
-  HIPCHECK(hipMemset(d_bad, 0, sizeof(u32)));
+  ix->d_segx.assign(T, NULL);
+  h->d_bad = dev_alloc<u32>(1);
+  HIPCHECK(hipMemset(h->d_bad, 0, sizeof(u32)));
   ix->ws.d_fcount = dev_alloc<u32>(4);
   ix->d_rows = dev_alloc<unsigned long long>(ANN_NCOUNTERS);
   HIPCHECK(hipMemset(ix->d_rows, 0, ANN_NCOUNTERS * sizeof(unsigned long long)));
-  TryInfo *solo = dev_alloc<TryInfo>(1);
-  DevBuf cand_d, cand_i, nvt, nvo, flist, xids, xd;
-  for (int t = 0; t < T; t++) {
-    HIPCHECK(hipMemsetAsync(cnt, 0, sizeof(u32) * nb, s));
-    HIPCHECK(hipMemsetAsync(cursor, 0, sizeof(u32) * nb, s));
-    HIPCHECK(hipMemsetAsync(d_max_cnt, 0, sizeof(u32), s));
-    bucket_count_kernel<<<grid_for(n, 256, 4096), 256, 0, s>>>(n, codes[t], cnt);
-    max_u32_kernel<<<grid_for(nb, 256, 1024), 256, 0, s>>>(nb, cnt, d_max_cnt);
-    u32 pm = 0;
-    HIPCHECK(hipMemcpyAsync(&pm, d_max_cnt, sizeof(u32), hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipStreamSynchronize(s));
-    if (pm == 0 || pm >= (1u << 20)) die("degenerate bucket table");
-    u32 *tab = dev_alloc<u32>(nb * pm);
-    fill_u32_kernel<<<grid_for(nb * pm, 256, 16384), 256, 0, s>>>(nb * pm, (u32)n, tab);
-    bucket_place_kernel<<<grid_for(n, 256, 4096), 256, 0, s>>>(n, pm, codes[t], cursor, tab);
-    bucket_order_kernel<<<grid_for(nb, 256, 1u << 30), 256, 0, s>>>(nb, pm, cnt, tab);
+  h->solo = dev_alloc<TryInfo>(1);
+  return h;
+}
+
+// out[0..5] = d_short, merged row stride Wn (entries), tries whose distance pass runs, tries, n, k
+extern "C" void annhip_precomp_info(const annhip_precomp *h, size_t out[6]) {
+  size_t v[6] = {h->ds, h->Wn, (size_t)h->tries_scored, (size_t)h->T, h->n, h->k};
+  memcpy(out, v, sizeof v);
+}
+
+// merged_i (u32, as int32 INT32_MAX) / merged_d (+inf) = "nobody computed this entry": the neutral elements of the MIN
+// all-reduce that follows the tries on a sharded host
+extern "C" void annhip_precomp_init_merged(annhip_precomp *h, uint32_t *merged_i_dev, ftype *merged_d_dev) {
+  RandGuard keep_callers_stream;
+  const size_t cnt = h->n * h->Wn;
+  fill_u32_kernel<<<grid_for(cnt, 256, 16384), 256, 0, h->s>>>(cnt, 0x7FFFFFFFu, merged_i_dev);
+  fill_ft_kernel<<<grid_for(cnt, 256, 16384), 256, 0, h->s>>>(cnt, ft_inf_host(), reinterpret_cast<FT *>(merged_d_dev));
+  HIPCHECK(hipGetLastError());
+}
+
+// run_initial of try t (alg.c:154-183) for rows [row_lo,row_hi): codes_dev[x - row_lo]; also save_vecs (alg.c:189-217)
+extern "C" void annhip_precomp_hash(annhip_precomp *h, int t, size_t row_lo, size_t row_hi, uint32_t *codes_dev) {
+  RandGuard keep_callers_stream;
+  if (t < 0 || t >= h->T || row_lo > row_hi || row_hi > h->n) die("annhip_precomp_hash: bad arguments");
+  const size_t d = h->d, ds = h->ds, d_max = h->d_max;
+  hipStream_t s = h->s;
+  std::vector<void *> owned;
+  const HostXform &hx = h->hx[t];
+  XformDev X;
+  X.b_i = upload_vec(hx.before.ci, owned), X.b_j = upload_vec(hx.before.cj, owned);
+  X.b_c = upload_vec(hx.before.c, owned), X.b_s = upload_vec(hx.before.s, owned);
+  X.a_i = upload_vec(hx.after.ci, owned), X.a_j = upload_vec(hx.after.cj, owned);
+  X.a_c = upload_vec(hx.after.c, owned), X.a_s = upload_vec(hx.after.s, owned);
+  X.perm_b = upload_vec(hx.perm_b, owned), X.perm_ai = upload_vec(hx.perm_ai, owned);
+  X.rots_b = (int)h->rots_before, X.rlb = (int)h->rot_len_before, X.rots_a = (int)h->rots_after, X.rla = (int)h->rot_len_after;
+  X.d = (int)d, X.d_max = (int)d_max, X.ds = (int)ds, X.l = ann_lg(d_max);
+  const int wpb = 4;
+  const size_t rows = row_hi - row_lo;
+  size_t smem = sizeof(FT) * wpb * (d + d_max + ds);
+  if (rows) {
+    allow_lds(hash_rows_kernel, smem);
+    hipLaunchKernelGGL(hash_rows_kernel, dim3((unsigned)((rows + wpb - 1) / wpb)), dim3(64 * wpb), smem, s, X, rows,
+                       h->centred + row_lo * d, codes_dev);
     HIPCHECK(hipGetLastError());
-    ix->d_tabs[t] = tab;
-    ix->h_tries[t].tab = tab;
-    ix->h_tries[t].pm = pm;
-    if (pm > 0xFFFFu) die("bucket too large");
-    ix->d_segs[t] = dev_alloc<uint2>(nb);
-    build_seg_kernel<<<grid_for(nb, 256, 1u << 30), 256, 0, s>>>(nb, pm, tab, (u32)n, 0u, (u32)n, ix->d_segs[t], d_bad);
-    ix->h_tries[t].seg = ix->d_segs[t];
-    ix->h_tries[t].segx = NULL;
-
-    // a one-try view of the index: candidate row = [ds+1][pm], codes are the points' own (no scramble)
-    TryInfo one;
-    one.seg = ix->d_segs[t];
-    one.segx = NULL;
-    one.tab = tab, one.pm = pm, one.off = 0, one.end = (u32)((ds + 1) * pm), one.magic = magic_for(pm);
-    if ((unsigned long long)one.end * pm >= (1ull << 32)) die("candidate row too long");
-    HIPCHECK(hipMemcpyAsync(solo, &one, sizeof one, hipMemcpyHostToDevice, s));
-    QParams P;
-    P.points = pts, P.tries = solo, P.graph = NULL, P.means = NULL, P.bases = NULL;
-    P.n = (u32)n, P.lo = 0, P.hi = (u32)n, P.d = (int)d, P.k = (int)k, P.T = 1, P.ds = (int)ds;
-    P.L1 = one.end, P.P1 = 1u << ann_lg(P.L1), P.Lc1 = (u32)ann_need_len(P.L1, k);
-    P.L2 = P.Lc2 = 0;
-    if (t >= tries_scored) {  // table, pm and segments are kept; nothing reads this try's merged columns
-      HIPCHECK(hipStreamSynchronize(s));
-      HIPCHECK(hipFree(codes[t]));
-      continue;
-    }
-    int mode = (exact_all || (u32)k > P.P1) ? 1 : 0;
-    FT *cd = NULL;
-    u32 *ci = NULL, *nv = NULL;
-    if (mode == 0) {
-      cd = (FT *)cand_d.need(sizeof(FT) * n * (k + 1));
-      ci = (u32 *)cand_i.need(sizeof(u32) * n * (k + 1));
-      nv = (u32 *)nvt.need(sizeof(u32) * n);
-      u32 *no = (u32 *)nvo.need(sizeof(u32) * n);
-      if (!launch_stage1_bucket(P, one, nb, cd, ci, nv, no, s))
-        launch_stage1(NULL, P, n, pts, 1, codes[t], cd, ci, nv, no, s, std::vector<TryInfo>(1, one), env().slot_scan ? 0 : 1);
-    }
-    finalize_and_fallback(NULL, P, n, pts, 1, codes[t], mode, cd, ci, nv, merged_i, merged_d, (int)Wn, (int)(t * k),
-                          flist, xids, xd, ix->ws.d_fcount, NULL, NULL, false, s);
-    HIPCHECK(hipStreamSynchronize(s));
-    HIPCHECK(hipFree(codes[t]));
   }
-  HIPCHECK(hipFree(cnt));
-  HIPCHECK(hipFree(cursor));
-  HIPCHECK(hipFree(d_max_cnt));
-  HIPCHECK(hipFree(solo));
-  {
-    u32 nbad = 0;
-    HIPCHECK(hipMemcpy(&nbad, d_bad, sizeof(u32), hipMemcpyDeviceToHost));
-    HIPCHECK(hipFree(d_bad));
-    if (nbad) die("internal error: a bucket table built by precomp is not in sorted-prefix layout");
-    ix->use_seg = env().slot_scan ? 0 : 1;
-    ix->d_segx.assign(T, NULL);
+  if (ds) {
+    smem = sizeof(FT) * wpb * (d + d_max);
+    allow_lds(bases_rows_kernel, smem);
+    hipLaunchKernelGGL(bases_rows_kernel, dim3((unsigned)((ds + wpb - 1) / wpb)), dim3(64 * wpb), smem, s, X,
+                       h->ix->d_bases + (size_t)t * ds * d);
+    HIPCHECK(hipGetLastError());
   }
-  cand_d.release(), cand_i.release(), nvt.release(), nvo.release(), flist.release(), xids.release(), xd.release();
-
-  // det_results on the merged rows (alg.c:419-422): distances are reused, graph == merged rows (Q16)
-  finish_geometry(ix);
-  u32 *top_i = dev_alloc<u32>(n * k);
-  FT *top_d = dev_alloc<FT>(n * k);
-  launch_exact_select((u32)W, (u32)std::min(need_W, Wn), (u32)Wn, (int)k, n, merged_i, merged_d, NULL, 0, top_i, top_d,
-                      (int)k, 0, s);
   HIPCHECK(hipStreamSynchronize(s));
+  for (void *p : owned) HIPCHECK(hipFree(p));
+}
+
+// second_half of try t (alg.c:245-290) from the codes of ALL n points: bucket table, then -- for the tries whose merged
+// columns are read at all -- each point's candidates -> its k best, into columns [t*k, (t+1)*k) of merged_i / merged_d
+// (row stride Wn).  On a sharded host only the members of this rank's buckets are scored (bucket b: rank b mod world).
+extern "C" void annhip_precomp_try(annhip_precomp *h, int t, const uint32_t *codes_dev, uint32_t *merged_i_dev,
+                                   ftype *merged_d_dev) {
+  RandGuard keep_callers_stream;
+  annhip_index *ix = h->ix;
+  const size_t n = h->n, k = h->k, d = h->d, ds = h->ds, nb = h->nb;
+  hipStream_t s = h->s;
+  const FT *pts = ix->d_points;
+  FT *merged_d = reinterpret_cast<FT *>(merged_d_dev);
+  HIPCHECK(hipMemsetAsync(h->cnt, 0, sizeof(u32) * nb, s));
+  HIPCHECK(hipMemsetAsync(h->cursor, 0, sizeof(u32) * nb, s));
+  HIPCHECK(hipMemsetAsync(h->d_max_cnt, 0, sizeof(u32), s));
+  bucket_count_kernel<<<grid_for(n, 256, 4096), 256, 0, s>>>(n, codes_dev, h->cnt);
+  max_u32_kernel<<<grid_for(nb, 256, 1024), 256, 0, s>>>(nb, h->cnt, h->d_max_cnt);
+  u32 pm = 0;
+  HIPCHECK(hipMemcpyAsync(&pm, h->d_max_cnt, sizeof(u32), hipMemcpyDeviceToHost, s));
+  HIPCHECK(hipStreamSynchronize(s));
+  if (pm == 0 || pm >= (1u << 20)) die("degenerate bucket table");
+  u32 *tab = dev_alloc<u32>(nb * pm);
+  fill_u32_kernel<<<grid_for(nb * pm, 256, 16384), 256, 0, s>>>(nb * pm, (u32)n, tab);
+  bucket_place_kernel<<<grid_for(n, 256, 4096), 256, 0, s>>>(n, pm, codes_dev, h->cursor, tab);
+  bucket_order_kernel<<<grid_for(nb, 256, 1u << 30), 256, 0, s>>>(nb, pm, h->cnt, tab);
+  HIPCHECK(hipGetLastError());
+  ix->d_tabs[t] = tab;
+  ix->h_tries[t].tab = tab;
+  ix->h_tries[t].pm = pm;
+  if (pm > 0xFFFFu) die("bucket too large");
+  ix->d_segs[t] = dev_alloc<uint2>(nb);
+  build_seg_kernel<<<grid_for(nb, 256, 1u << 30), 256, 0, s>>>(nb, pm, tab, (u32)n, 0u, (u32)n, ix->d_segs[t], h->d_bad);
+  ix->h_tries[t].seg = ix->d_segs[t];
+  ix->h_tries[t].segx = NULL;
+  if (t >= h->tries_scored) {  // table, pm and segments are kept; nothing reads this try's merged columns
+    HIPCHECK(hipStreamSynchronize(s));
+    return;
+  }
+  // a one-try view of the index: candidate row = [ds+1][pm], codes are the points' own (no scramble)
+  TryInfo one;
+  one.seg = ix->d_segs[t];
+  one.segx = NULL;
+  one.tab = tab, one.pm = pm, one.off = 0, one.end = (u32)((ds + 1) * pm), one.magic = magic_for(pm);
+  if ((unsigned long long)one.end * pm >= (1ull << 32)) die("candidate row too long");
+  HIPCHECK(hipMemcpyAsync(h->solo, &one, sizeof one, hipMemcpyHostToDevice, s));
+  QParams P;
+  P.points = pts, P.tries = h->solo, P.graph = NULL, P.means = NULL, P.bases = NULL;
+  P.n = (u32)n, P.lo = 0, P.hi = (u32)n, P.d = (int)d, P.k = (int)k, P.T = 1, P.ds = (int)ds;
+  P.L1 = one.end, P.P1 = 1u << ann_lg(P.L1), P.Lc1 = (u32)ann_need_len(P.L1, k);
+  P.L2 = P.Lc2 = 0;
+  int mode = (h->exact_all || (u32)k > P.P1) ? 1 : 0;
+  FT *cd = NULL;
+  u32 *ci = NULL, *nv = NULL;
+  if (mode == 0) {
+    cd = (FT *)h->cand_d.need(sizeof(FT) * n * (k + 1));
+    ci = (u32 *)h->cand_i.need(sizeof(u32) * n * (k + 1));
+    nv = (u32 *)h->nvt.need(sizeof(u32) * n);
+    u32 *no = (u32 *)h->nvo.need(sizeof(u32) * n);
+    // sharded: rows whose bucket belongs to another rank keep this marker and are skipped by finalize1
+    if (h->world > 1) mark_rows_kernel<<<grid_for(n, 256, 16384), 256, 0, s>>>(n, (u32)(k + 1), ANN_ID_SKIP, ci);
+    if (!launch_stage1_bucket(P, one, nb, cd, ci, nv, no, s, (u32)h->rank, (u32)h->world)) {
+      // shapes the bucket kernel does not take: every rank scores every row (the exchange is then a no-op for this try)
+      launch_stage1(NULL, P, n, pts, 1, codes_dev, cd, ci, nv, no, s, std::vector<TryInfo>(1, one), env().slot_scan ? 0 : 1);
+    }
+  }
+  finalize_and_fallback(NULL, P, n, pts, 1, codes_dev, mode, cd, ci, nv, merged_i_dev, merged_d, (int)h->Wn, (int)(t * k),
+                        h->flist, h->xids, h->xd, ix->ws.d_fcount, NULL, NULL, false, s);
+  HIPCHECK(hipStreamSynchronize(s));
+}
+
+// det_results on the merged rows (alg.c:419-422), part 1: the network over each point's k*T' merged entries (distances
+// are reused, not recomputed, alg.c:308-312) -- every rank, all rows.
+extern "C" void annhip_precomp_merge(annhip_precomp *h, uint32_t *merged_i_dev, ftype *merged_d_dev) {
+  RandGuard keep_callers_stream;
+  annhip_index *ix = h->ix;
+  const size_t n = h->n, k = h->k;
+  hipStream_t s = h->s;
+  u32 nbad = 0;
+  HIPCHECK(hipMemcpy(&nbad, h->d_bad, sizeof(u32), hipMemcpyDeviceToHost));
+  if (nbad) die("internal error: a bucket table built by precomp is not in sorted-prefix layout");
+  ix->use_seg = env().slot_scan ? 0 : 1;
+  h->cand_d.release(), h->cand_i.release(), h->nvt.release(), h->nvo.release(), h->flist.release(), h->xids.release(),
+      h->xd.release();
+  if (h->centred) HIPCHECK(hipFree(h->centred));
+  h->centred = NULL;
+  finish_geometry(ix);
+  h->top_i = dev_alloc<u32>(n * k);
+  h->top_d = dev_alloc<FT>(n * k);
+  launch_exact_select((u32)h->W, (u32)std::min(h->need_W, h->Wn), (u32)h->Wn, (int)k, n, merged_i_dev,
+                      reinterpret_cast<FT *>(merged_d_dev), NULL, 0, h->top_i, h->top_d, (int)k, 0, s);
+  HIPCHECK(hipStreamSynchronize(s));
+}
+
+// part 2 for rows [row_lo,row_hi): neighbour rows = the first k entries of the OTHER points' merged, sorted rows (Q16),
+// distances, network -> graph_dev u32[(row_hi-row_lo)][k] and graph_dists_dev (may be NULL)
+extern "C" void annhip_precomp_graph(annhip_precomp *h, size_t row_lo, size_t row_hi, uint32_t *graph_dev,
+                                     ftype *graph_dists_dev) {
+  RandGuard keep_callers_stream;
+  annhip_index *ix = h->ix;
+  const size_t n = h->n, k = h->k;
+  if (row_lo > row_hi || row_hi > n) die("annhip_precomp_graph: bad row range");
+  hipStream_t s = h->s;
+  QParams P = make_params(ix);
+  P.graph = h->top_i;
+  FT *gd_own = graph_dists_dev ? NULL : dev_alloc<FT>((row_hi - row_lo) * k + 1);
+  FT *gd = graph_dists_dev ? reinterpret_cast<FT *>(graph_dists_dev) : gd_own;
+  const size_t row_bytes = (size_t)P.Lc2 * (sizeof(FT) + sizeof(u32));
+  size_t chunk = ((size_t)2 << 30) / row_bytes;
+  if (chunk < 1) chunk = 1;
+  DevBuf r2i, r2d;
+  for (size_t q0 = row_lo; q0 < row_hi; q0 += chunk) {
+    const size_t nq = std::min(chunk, row_hi - q0);
+    u32 *ri = (u32 *)r2i.need(sizeof(u32) * nq * P.Lc2);
+    FT *rd = (FT *)r2d.need(sizeof(FT) * nq * P.Lc2);
+    launch_rows<MODE_GRAPH>(P, n, ix->d_points, 1, NULL, NULL, (u32)q0, nq, P.Lc2, h->top_i, h->top_d, ri, rd, NULL, s);
+    // outputs are indexed by the global row x: offset the slices so that row x lands at (x - row_lo)
+    launch_exact_select(P.L2, P.Lc2, P.Lc2, (int)k, nq, ri, rd, NULL, (u32)q0, graph_dev - row_lo * k, gd - row_lo * k,
+                        (int)k, 0, s);
+  }
+  HIPCHECK(hipStreamSynchronize(s));
+  r2i.release(), r2d.release();
+  if (gd_own) HIPCHECK(hipFree(gd_own));
+}
+
+// the resident index; graph_dev u32[n][k] is copied in
+extern "C" annhip_index *annhip_precomp_finish(annhip_precomp *h, const uint32_t *graph_dev) {
+  RandGuard keep_callers_stream;
+  annhip_index *ix = h->ix;
+  ix->d_graph = dev_alloc<u32>(h->n * h->k);
+  HIPCHECK(hipMemcpy(ix->d_graph, graph_dev, sizeof(u32) * h->n * h->k, hipMemcpyDeviceToDevice));
+  if (h->top_i) HIPCHECK(hipFree(h->top_i));
+  if (h->top_d) HIPCHECK(hipFree(h->top_d));
+  if (h->centred) HIPCHECK(hipFree(h->centred));
+  HIPCHECK(hipFree(h->cnt));
+  HIPCHECK(hipFree(h->cursor));
+  HIPCHECK(hipFree(h->d_max_cnt));
+  HIPCHECK(hipFree(h->d_bad));
+  HIPCHECK(hipFree(h->solo));
+  delete h;
+  return ix;
+}
+
+extern "C" annhip_index *annhip_precomp_index(size_t n, size_t k, size_t d, const ftype *points, int on_device,
+                                              int tries, size_t rots_before, size_t rot_len_before,
+                                              size_t rots_after, size_t rot_len_after, ftype *graph_dists_dev) {
+  annhip_precomp *h = annhip_precomp_begin(n, k, d, points, on_device, tries, rots_before, rot_len_before, rots_after,
+                                           rot_len_after, 0, 1);
+  RandGuard keep_callers_stream;
+  u32 *merged_i = dev_alloc<u32>(n * h->Wn);
+  FT *merged_d = dev_alloc<FT>(n * h->Wn);
+  u32 *codes = dev_alloc<u32>(n);
+  for (int t = 0; t < tries; t++) {
+    annhip_precomp_hash(h, t, 0, n, codes);
+    annhip_precomp_try(h, t, codes, merged_i, reinterpret_cast<ftype *>(merged_d));
+  }
+  HIPCHECK(hipFree(codes));
+  annhip_precomp_merge(h, merged_i, reinterpret_cast<ftype *>(merged_d));
   HIPCHECK(hipFree(merged_i));
   HIPCHECK(hipFree(merged_d));
-  ix->d_graph = dev_alloc<u32>(n * k);
+  u32 *graph = dev_alloc<u32>(n * k);
   FT *gd = graph_dists_dev ? reinterpret_cast<FT *>(graph_dists_dev) : dev_alloc<FT>(n * k);
-  {
-    QParams P = make_params(ix);
-    P.graph = top_i;  // neighbour rows = first k entries of the other points' merged, sorted rows
-    const size_t row_bytes = (size_t)P.Lc2 * (sizeof(FT) + sizeof(u32));
-    size_t chunk = ((size_t)2 << 30) / row_bytes;
-    if (chunk < 1) chunk = 1;
-    DevBuf r2i, r2d;
-    for (size_t q0 = 0; q0 < n; q0 += chunk) {
-      const size_t nq = std::min(chunk, n - q0);
-      u32 *ri = (u32 *)r2i.need(sizeof(u32) * nq * P.Lc2);
-      FT *rd = (FT *)r2d.need(sizeof(FT) * nq * P.Lc2);
-      launch_rows<MODE_GRAPH>(P, n, pts, 1, NULL, NULL, (u32)q0, nq, P.Lc2, top_i, top_d, ri, rd, NULL, s);
-      launch_exact_select(P.L2, P.Lc2, P.Lc2, (int)k, nq, ri, rd, NULL, (u32)q0, ix->d_graph, gd, (int)k, 0, s);
-    }
-    HIPCHECK(hipStreamSynchronize(s));
-    r2i.release(), r2d.release();
-  }
-  HIPCHECK(hipFree(top_i));
-  HIPCHECK(hipFree(top_d));
+  annhip_precomp_graph(h, 0, n, graph, reinterpret_cast<ftype *>(gd));
+  annhip_index *ix = annhip_precomp_finish(h, graph);
+  HIPCHECK(hipFree(graph));
   if (!graph_dists_dev) ix->d_graph_dists = gd;
   return ix;
 }

@@ -162,6 +162,11 @@ __global__ void fill_u32_kernel(size_t count, u32 value, u32 *out) {
        e += (size_t)gridDim.x * blockDim.x)
     out[e] = value;
 }
+__global__ void fill_ft_kernel(size_t count, FT value, FT *out) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count;
+       e += (size_t)gridDim.x * blockDim.x)
+    out[e] = value;
+}
 __global__ void bucket_count_kernel(size_t n, const u32 *__restrict__ codes, u32 *cnt) {
   for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x)
     atomicAdd(&cnt[codes[j]], 1u);

@@ -805,12 +805,14 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
 template <int D>
 __global__ __launch_bounds__(64 * ANN_BK_WAVES) void stage1_bucket_kernel(QParams P, int K1, u32 list_cap,
                                                             FT *__restrict__ cand_dist, u32 *__restrict__ cand_id,
-                                                            u32 *__restrict__ nv_tot, u32 *__restrict__ nv_own) {
+                                                            u32 *__restrict__ nv_tot, u32 *__restrict__ nv_own,
+                                                            u32 brem, u32 bmod) {
   typedef RowLay<D> L;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = lane_id(), w = threadIdx.x >> 6, W = blockDim.x >> 6;
   const TryInfo tr = P.tries[0];  // one-try view
   const u32 b = blockIdx.x, pm = tr.pm;
+  if (bmod > 1 && b % bmod != brem) return;  // sharded precomp: this bucket is scored by another rank
   const u32 members = tr.seg[b].y;  // valid ids of this bucket (in precomp the owned range is everything)
   if (members == 0) return;
   constexpr int CH = D / ANN_VEC;        // chunks per row
@@ -916,6 +918,11 @@ __global__ __launch_bounds__(64 * ANN_BK_WAVES) void stage1_bucket_kernel(QParam
 // (a tie between different ids is ordered by the network), and (c) the sorted prefix holds at
 // least one +inf entry or the row ends at P1 (otherwise the duplicate test at P1-1 reads slot P1's id).
 // Then the output is simply the first k keys.  Otherwise the query is appended to `flist`.
+#define ANN_ID_SKIP 0xFFFFFFFDu  // cand_id[x][0] of a row another rank of a sharded precomp is responsible for
+__global__ void mark_rows_kernel(size_t rows, u32 stride, u32 value, u32 *out) {
+  for (size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x; x < rows; x += (size_t)gridDim.x * blockDim.x)
+    out[x * stride] = value;
+}
 __global__ void finalize1_kernel(int Q, int k, int K1, u32 L1, u32 P1, const FT *__restrict__ cand_dist,
                                  const u32 *__restrict__ cand_id, const u32 *__restrict__ nv_tot,
                                  u32 *__restrict__ top_id, FT *__restrict__ top_dist, int ostride,
@@ -925,6 +932,7 @@ __global__ void finalize1_kernel(int Q, int k, int K1, u32 L1, u32 P1, const FT 
   if (x >= Q) return;
   const FT *cd = cand_dist + (size_t)x * K1;
   const u32 *ci = cand_id + (size_t)x * K1;
+  if (ci[0] == ANN_ID_SKIP) return;  // not this rank's row: neither accepted nor flagged
   bool flag = (u32)k > P1 || K1 != k + 1;
   int m = 0;
   while (m < K1 && ci[m] != ANN_ID_NONE) m++;

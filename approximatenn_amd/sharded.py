@@ -389,3 +389,89 @@ class ShardedQuery:
     def query(self, y, alias=False):
         """y: [Q,d] (identical on every rank).  Returns (ids int64 [Q,k], squared distances [Q,k])."""
         return self.collect(self.submit(y, alias))
+
+
+def precomp_sharded(points, k, tries=10, rots_before=6, rot_len_before=1, rots_after=1, rot_len_after=1, dist=None,
+                    group=None, want_dists=False, _begin_hook=None):
+    """precomp() with its distance passes spread over the ranks (include/ann_hip.h: annhip_precomp_begin ... _finish).
+
+    points: torch device tensor [n,d], ALL rows, identical on every rank (the build needs every row on every GPU; the
+    query path afterwards keeps only a row shard, Index.reshard).  Every rank must have seeded libc random() identically:
+    the rotations are drawn from it, in the reference's order.  Returns an Index holding the complete index, bit-identical
+    to the single-GPU build -- and to the reference's -- whatever the world size.  Three kinds of collectives: an
+    all-gather of the hash codes per try (4 B / point), ONE MIN all-reduce pair over the merged candidate rows (every
+    entry has exactly one writer: bucket b is scored by rank b mod world), an all-gather of the graph rows.
+    _begin_hook: called right before annhip_precomp_begin (tests with several ranks in one process seed random() there)."""
+    import ctypes as C
+
+    from . import _lib
+    from .api import Index
+    prec = "f32" if points.dtype == torch.float32 else "f64"
+    lib = _lib.load(prec)
+    assert points.is_cuda and points.is_contiguous()
+    on = dist is not None and dist.is_initialized() and dist.get_world_size(group) > 1
+    world = dist.get_world_size(group) if on else 1
+    rank = dist.get_rank(group) if on else 0
+    via_cpu = on and dist.get_backend(group) == "gloo"
+    n, d = points.shape
+    if _begin_hook is not None:
+        _begin_hook()
+    h = lib.annhip_precomp_begin(n, k, d, points.data_ptr(), 1, tries, rots_before, rot_len_before, rots_after,
+                                 rot_len_after, rank, world)
+    info = (C.c_size_t * 6)()
+    lib.annhip_precomp_info(h, C.byref(info))
+    Wn = int(info[1])
+    dev, i32 = points.device, torch.int32
+
+    def all_gather(out, inp):
+        if not on:
+            out.copy_(inp.reshape(out.shape))
+        elif via_cpu:
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(o, inp.cpu(), group=group)
+            out.copy_(o)
+        else:
+            dist.all_gather_into_tensor(out, inp, group=group)
+
+    def all_min(t):
+        if not on:
+            return
+        if via_cpu:
+            c = t.cpu()
+            dist.all_reduce(c, op=dist.ReduceOp.MIN, group=group)
+            t.copy_(c)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+
+    rows_per = (n + world - 1) // world
+    lo = min(n, rank * rows_per)
+    hi = min(n, lo + rows_per)
+    mi = torch.empty((n, Wn), dtype=i32, device=dev)
+    md = torch.empty((n, Wn), dtype=points.dtype, device=dev)
+    if on:
+        lib.annhip_precomp_init_merged(h, mi.data_ptr(), md.data_ptr())
+    codes_slice = torch.zeros((rows_per,), dtype=i32, device=dev)
+    codes_all = torch.empty((world * rows_per,), dtype=i32, device=dev)
+    for t in range(tries):
+        lib.annhip_precomp_hash(h, t, lo, hi, codes_slice.data_ptr())
+        all_gather(codes_all, codes_slice)
+        lib.annhip_precomp_try(h, t, codes_all.data_ptr(), mi.data_ptr(), md.data_ptr())
+    torch.cuda.synchronize(dev)
+    all_min(mi)
+    all_min(md)
+    torch.cuda.synchronize(dev)
+    lib.annhip_precomp_merge(h, mi.data_ptr(), md.data_ptr())
+    del mi, md
+    g_slice = torch.zeros((rows_per, k), dtype=i32, device=dev)
+    gd_slice = torch.zeros((rows_per, k), dtype=points.dtype, device=dev)
+    lib.annhip_precomp_graph(h, lo, hi, g_slice.data_ptr(), gd_slice.data_ptr())
+    g_all = torch.empty((world * rows_per, k), dtype=i32, device=dev)
+    all_gather(g_all, g_slice)
+    gd_all = None
+    if want_dists:
+        gd_all = torch.empty((world * rows_per, k), dtype=points.dtype, device=dev)
+        all_gather(gd_all, gd_slice)
+    torch.cuda.synchronize(dev)
+    ix = Index(prec, lib.annhip_precomp_finish(h, g_all.data_ptr()), keep=(points,))
+    ix.graph_dists = gd_all[:n] if want_dists else None
+    return ix

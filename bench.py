@@ -16,7 +16,8 @@ candidates travel to each query's owner rank by an RCCL all-to-all over xGMI and
 ids are all-gathered, partial stage-2 rows go back to the owners the same way, results are all-gathered
 (approximatenn_amd/sharded.py).  The batch grows with N (Q = 10k x N queries per step, every rank sees all of them),
 so per-GPU gather work stays fixed: "scaling": "weak".  value = total queries / max-over-ranks time.  The extra object
-"strong" reports the same job with the batch FIXED at 10k queries in total.
+"strong" reports the same job with the batch FIXED at 10k queries in total.  The index is built by all ranks together
+(precomp_sharded: every rank holds all rows during the build, the distance passes are dealt out by bucket).
 
 The JSON line also carries
   roofline     : the dominant kernel (stage1_select) priced at its ALGORITHMIC bytes / HIP-event duration
@@ -153,7 +154,11 @@ def main():
             torch.cuda.synchronize()
     datagen_s = time.time() - t0
     t0 = time.time()
-    ix = A.Index.precomp(points, k, T)          # draws its rotations from the same random() stream (Q12)
+    if sharded:                                 # distance passes dealt to the ranks by bucket; three collectives
+        from approximatenn_amd.sharded import precomp_sharded
+        ix = precomp_sharded(points, k, T, dist=dist)
+    else:
+        ix = A.Index.precomp(points, k, T)      # draws its rotations from the same random() stream (Q12)
     with park_random():
         torch.cuda.synchronize()
         precomp_s = time.time() - t0

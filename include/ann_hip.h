@@ -66,6 +66,29 @@ annhip_index *annhip_precomp_index(size_t n, size_t k, size_t d, const ftype *po
                                    size_t rot_len_before, size_t rots_after, size_t rot_len_after,
                                    ftype *graph_dists_dev);
 
+/* precomp() in phases, for point-sharded hosts (one process per GPU; EVERY rank holds all n rows during the build and
+ * draws the same rotations from the same random() seed).  Between the phases the host runs three collectives:
+ *     h = annhip_precomp_begin(..., rank, world);  annhip_precomp_info(h, info);  annhip_precomp_init_merged(h, mi, md);
+ *     for t in tries:  annhip_precomp_hash(h, t, lo, hi, codes_slice)     -> ALL-GATHER codes_all u32[n]
+ *                      annhip_precomp_try(h, t, codes_all, mi, md)        (this rank's buckets: b mod world == rank)
+ *     MIN ALL-REDUCE of mi (as int32) and md                               (every entry has exactly one writer)
+ *     annhip_precomp_merge(h, mi, md);  annhip_precomp_graph(h, lo, hi, graph_slice, dists_slice)
+ *                                                                          -> ALL-GATHER graph u32[n][k] (+ distances)
+ *     ix = annhip_precomp_finish(h, graph_all);
+ * mi u32[n][Wn], md ftype[n][Wn] with Wn = info[1]; info = {d_short, Wn, tries scored, tries, n, k}.
+ * annhip_precomp_index() is exactly this sequence with world = 1.  Results are identical for any world size. */
+typedef struct annhip_precomp annhip_precomp;
+annhip_precomp *annhip_precomp_begin(size_t n, size_t k, size_t d, const ftype *points, int points_on_device, int tries,
+                                     size_t rots_before, size_t rot_len_before, size_t rots_after, size_t rot_len_after,
+                                     int rank, int world);
+void annhip_precomp_info(const annhip_precomp *h, size_t out[6]);
+void annhip_precomp_init_merged(annhip_precomp *h, uint32_t *merged_i_dev, ftype *merged_d_dev);
+void annhip_precomp_hash(annhip_precomp *h, int t, size_t row_lo, size_t row_hi, uint32_t *codes_dev);
+void annhip_precomp_try(annhip_precomp *h, int t, const uint32_t *codes_dev, uint32_t *merged_i_dev, ftype *merged_d_dev);
+void annhip_precomp_merge(annhip_precomp *h, uint32_t *merged_i_dev, ftype *merged_d_dev);
+void annhip_precomp_graph(annhip_precomp *h, size_t row_lo, size_t row_hi, uint32_t *graph_dev, ftype *graph_dists_dev);
+annhip_index *annhip_precomp_finish(annhip_precomp *h, const uint32_t *graph_dev);
+
 /* ---- whole query on one device (alg.c:458-519) ------------------------------------------------- */
 /* y_dev: ftype[ycnt][d]; alias != 0: query x excludes point x (the y == points case, compute.cl:144-146).
  * mode 0: selection path with exact fallback; mode 1: exact path for every query.

@@ -190,3 +190,78 @@ def test_small_shards_with_a_heavy_bucket(prec):
     for world in (4, 8):
         for ids, dd, _ in _run_sharded(prec, o_save, pts, y, world):
             assert np.array_equal(ids, want[0]) and bits_equal(dd, want[1]), world
+
+
+@pytest.mark.parametrize("name,world", [("pow2_d64_f32", 2), ("pow2_d128_f64", 3), ("pow2_d32_f32", 4), ("defaults_d80_f32", 2),
+                                        ("k17_d100_f64", 2)])
+def test_sharded_precomp_matches_golden(name, world):
+    """precomp with its distance passes dealt to the ranks by bucket (power-of-two d) -- or run redundantly where the
+    bucket kernel does not apply (d = 80, 100) -- gives the reference's index on every rank, field for field."""
+    from approximatenn_amd.sharded import precomp_sharded
+    from tests.util import assert_save_equal
+    g = load_golden(name)
+    c, prec = g["cfg"], g["prec"]
+    pts = torch.from_numpy(np.ascontiguousarray(g["points"])).cuda()
+    td = ThreadDist(world)
+    lock = threading.Lock()
+    results, errors = [None] * world, []
+
+    def seed():    # every "rank" starts from the libc stream position the golden generator had after drawing the points
+        O.srandom(c["seed"])
+        orc = O.CpuBackend(prec, "oracle")
+        orc.rand_norm_reset()
+        orc.gen_rand(c["n"] * c["d"] + (c["n"] * c["d"]) % 2)
+
+    def work(rank):
+        try:
+            td.tl.rank = rank
+            lock.acquire()     # ranks share one process, hence one random() stream: seed + draw one rank at a time
+            ix = _precomp_with_lock(precomp_sharded, lock, pts, c, dict(dist=td, want_dists=True, _begin_hook=seed))
+            save = ix.export()
+            results[rank] = (save.to_dict(), ix.graph_dists.cpu().numpy())
+            y = torch.from_numpy(np.ascontiguousarray(g["y"])).cuda()
+            ids, dd, _ = ix.query(y)
+            torch.cuda.synchronize()
+            assert np.array_equal(ids.cpu().numpy().astype(np.uint64), g["query_ids"]) and bits_equal(dd.cpu().numpy(), g["query_dists"])
+            save.free()
+            ix.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            td.bar.abort()
+            if lock.locked():
+                try:
+                    lock.release()
+                except RuntimeError:
+                    pass
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
+    for sd, gdists in results:
+        assert_save_equal(sd, g["save"])
+        assert bits_equal(gdists, g["precomp_dists"])
+
+
+def _precomp_with_lock(precomp_sharded, lock, pts, c, kw):
+    """Run precomp_sharded with the caller HOLDING `lock`; the lock is released as soon as annhip_precomp_begin (the only
+    consumer of the process-wide random() stream) has returned, i.e. at the first collective."""
+    td = kw["dist"]
+    released = []
+    orig = td.all_gather_into_tensor
+
+    def first_collective(out, t, group=None):
+        if not released:
+            released.append(1)
+            lock.release()
+        return orig(out, t, group=group)
+    proxy = _Proxy(td, first_collective)
+    kw = dict(kw, dist=proxy)
+    return precomp_sharded(pts, c["k"], c["tries"], c["rb"], c["rlb"], c["ra"], c["rla"], **kw)
+
+
+class _Proxy:
+    def __init__(self, td, ag):
+        self._td, self.all_gather_into_tensor = td, ag
+
+    def __getattr__(self, name):
+        return getattr(self._td, name)
