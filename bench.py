@@ -112,7 +112,9 @@ def main():
                 opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
             except Exception:  # noqa: BLE001
                 pass
-            dist.init_process_group(backend="nccl", pg_options=opts, device_id=device)
+            import datetime
+            # a rank that dies must not leave the others waiting for the default 10 minutes
+            dist.init_process_group(backend="nccl", pg_options=opts, device_id=device, timeout=datetime.timedelta(seconds=240))
 
     n, d, k, T = args.n, args.d, args.k, args.tries
     tdt = torch.float32 if args.dtype == "f32" else torch.float64
