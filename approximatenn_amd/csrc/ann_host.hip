@@ -728,6 +728,27 @@ static void launch_exact_select(u32 L, u32 len, u32 in_stride, int k, size_t nq,
   HIPCHECK(hipGetLastError());
 }
 
+// the whole of stage 2 for queries [xbase, xbase + nq) in one launch (needs Lc2 <= 1024: the row lives in LDS)
+template <typename IdOut>
+static void launch_stage2_fused(const QParams &P, size_t Q, const FT *y, int alias, u32 xbase, size_t nq, const u32 *top_i,
+                                const FT *top_d, IdOut *out_ids, FT *out_d, unsigned long long *rows_ctr, hipStream_t s) {
+  if (!nq) return;
+  size_t smem = sizeof(Key) * (size_t)P.k + 3 * sizeof(u32) * (size_t)P.Lc2 + 16;
+  smem = (smem + 15) & ~(size_t)15;
+  smem += sizeof(FT) * (size_t)P.Lc2;
+  smem = (smem + 15) & ~(size_t)15;
+  if (d_needs_lds_row(P.d)) smem += sizeof(FT) * (size_t)P.d * 3;
+#define CALL(DD)                                                                                                   \
+  do {                                                                                                             \
+    allow_lds((stage2_fused_kernel<DD, IdOut>), smem);                                                             \
+    hipLaunchKernelGGL((stage2_fused_kernel<DD, IdOut>), dim3((unsigned)nq), dim3(128), smem, s, P, (int)Q, y, alias, \
+                       top_i, top_d, P.Lc2, out_ids, out_d, rows_ctr, xbase);                                      \
+  } while (0)
+  ANN_DISPATCH_D(P.d, CALL);
+#undef CALL
+  HIPCHECK(hipGetLastError());
+}
+
 // finalize + exact fallback for the queries finalize1 rejected.  The top-k lands in top_i/top_d
 // (row stride ostride, column offset ooff).  device_driven: no host read-back -- the exact-path kernels are
 // launched over the worst case (every query rejected) and rows beyond the device-side count exit at once;
@@ -882,20 +903,7 @@ static long query_impl(annhip_index *ix, annhip_workspace &ws, hipStream_t s, si
   FT *out_d = dists_dev ? reinterpret_cast<FT *>(dists_dev) : (FT *)ws.out_d.need(sizeof(FT) * Q * k);
   if (ix->lo == 0 && ix->hi == ix->n && P.Lc2 <= 1024 && env().tail != 0) {
     // one kernel: row assembly, neighbour gathers, network and size_t ids per query (stage2_fused_kernel)
-    size_t smem = sizeof(Key) * (size_t)k + 3 * sizeof(u32) * (size_t)P.Lc2 + 16;
-    smem = (smem + 15) & ~(size_t)15;
-    smem += sizeof(FT) * (size_t)P.Lc2;
-    smem = (smem + 15) & ~(size_t)15;
-    if (d_needs_lds_row(P.d)) smem += sizeof(FT) * (size_t)P.d * 3;
-#define CALL(DD)                                                                                               \
-  do {                                                                                                         \
-    allow_lds(stage2_fused_kernel<DD>, smem);                                                                  \
-    hipLaunchKernelGGL(stage2_fused_kernel<DD>, dim3((unsigned)Q), dim3(128), smem, s, P, (int)Q, y, alias, top_i, \
-                       top_d, P.Lc2, ids_dev, out_d, rows_ctr);                                                \
-  } while (0)
-    ANN_DISPATCH_D(P.d, CALL);
-#undef CALL
-    HIPCHECK(hipGetLastError());
+    launch_stage2_fused<size_t>(P, Q, y, alias, 0, Q, top_i, top_d, ids_dev, out_d, rows_ctr, s);
     seg_mark(ix, marks, s);  // "stage2_rows" = the whole fused stage 2; "stage2_network" and "widen" stay 0
     seg_mark(ix, marks, s);
     seg_mark(ix, marks, s);
@@ -1594,6 +1602,16 @@ extern "C" void annhip_precomp_graph(annhip_precomp *h, size_t row_lo, size_t ro
   P.graph = h->top_i;
   FT *gd_own = graph_dists_dev ? NULL : dev_alloc<FT>((row_hi - row_lo) * k + 1);
   FT *gd = graph_dists_dev ? reinterpret_cast<FT *>(graph_dists_dev) : gd_own;
+  if (P.Lc2 <= 1024 && env().tail != 0) {  // the fused stage-2 kernel: the [rows][Lc2] rows never travel through HBM
+    for (size_t q0 = row_lo; q0 < row_hi; q0 += (size_t)1 << 30) {
+      const size_t nq = std::min((size_t)1 << 30, row_hi - q0);
+      launch_stage2_fused<u32>(P, n, ix->d_points, 1, (u32)q0, nq, h->top_i, h->top_d, graph_dev - row_lo * k, gd - row_lo * k,
+                               NULL, s);
+    }
+    HIPCHECK(hipStreamSynchronize(s));
+    if (gd_own) HIPCHECK(hipFree(gd_own));
+    return;
+  }
   const size_t row_bytes = (size_t)P.Lc2 * (sizeof(FT) + sizeof(u32));
   size_t chunk = ((size_t)2 << 30) / row_bytes;
   if (chunk < 1) chunk = 1;

@@ -371,11 +371,11 @@ __device__ __forceinline__ void gather_select(const QParams &P, const u32 *list,
 // compute.cl:252-263); distances of the new slots gathered here (owned, valid, not the excluded self: else +inf);
 // the reference's network + rdups + network in LDS (alg.c:224-230); first k entries to out_ids/out_dist[x].
 // t_* and cnt2p are LDS scratch (len2 entries each; *cnt2p must be 0 on entry).  Returns the rows gathered.
-template <int D>
+template <int D, typename IdOut>
 __device__ __forceinline__ u32 stage2_in_workgroup(const QParams &P, u32 x, int alias, const VT (&a)[RowChunks<D>::C],
                                                    const FT *yq, FT *scratch, const Key *top, int k, u32 len2,
                                                    u32 *t_ids, u32 *t_slot, u32 *t_gid, FT *t_dist, u32 *cnt2p,
-                                                   size_t *__restrict__ out_ids, FT *__restrict__ out_dist) {
+                                                   IdOut *__restrict__ out_ids, FT *__restrict__ out_dist) {
   const int lane = lane_id(), w = threadIdx.x >> 6, W = blockDim.x >> 6;
   for (u32 j = threadIdx.x; j < len2; j += blockDim.x) {
     u32 id;
@@ -445,15 +445,17 @@ __device__ __forceinline__ u32 stage2_in_workgroup(const QParams &P, u32 x, int 
 // Stage 2 as ONE kernel (single-device query path, stage-2 rows that fit LDS): per query the row assembly, the <= k*k
 // neighbour gathers, the network and the size_t ids -- what row_dists<GRAPH> + exact_select + widen_ids did with three
 // launches and two round trips of the [Q][Lc2] rows through HBM (cfg3: 58 + 33 + 6 us -> one ~60 us kernel).
-template <int D>
+// IdOut = size_t: query() results (the ABI's ids); u32: precomp's graph rows.  Query x = xbase + blockIdx.x; outputs are
+// indexed by x.
+template <int D, typename IdOut>
 __global__ __launch_bounds__(128) void stage2_fused_kernel(QParams P, int Q, const FT *__restrict__ y, int alias,
                                                            const u32 *__restrict__ top_id, const FT *__restrict__ top_dist,
-                                                           u32 len2, size_t *__restrict__ out_ids,
+                                                           u32 len2, IdOut *__restrict__ out_ids,
                                                            FT *__restrict__ out_dist,
-                                                           unsigned long long *__restrict__ rows_done) {
+                                                           unsigned long long *__restrict__ rows_done, u32 xbase) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = lane_id(), w = threadIdx.x >> 6;
-  const u32 x = blockIdx.x;
+  const u32 x = xbase + blockIdx.x;
   const int k = P.k;
   unsigned char *sp = smem;
   Key *top = reinterpret_cast<Key *>(sp);     sp += sizeof(Key) * (size_t)k;
@@ -482,8 +484,8 @@ __global__ __launch_bounds__(128) void stage2_fused_kernel(QParams P, int Q, con
     for (int c = 0; c < OcCode<D>::C; c++) a[c] = yp[c * ol.oc];
   }
   __syncthreads();
-  const u32 got = stage2_in_workgroup<D>(P, x, alias, a, yq, yq + (size_t)(1 + w) * P.d, top, k, len2, t_ids, t_slot, t_gid,
-                                         t_dist, cnt2, out_ids, out_dist);
+  const u32 got = stage2_in_workgroup<D, IdOut>(P, x, alias, a, yq, yq + (size_t)(1 + w) * P.d, top, k, len2, t_ids, t_slot,
+                                                t_gid, t_dist, cnt2, out_ids, out_dist);
   if (rows_done && threadIdx.x == 0) atomicAdd(&rows_done[(x & 63u) * 8u], (unsigned long long)got);
 }
 
@@ -769,8 +771,8 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
   }
   // ---- fused stage 2 (det_results second half, alg.c:314-327) on this query's own workgroup
   {
-    const u32 cnt2 = stage2_in_workgroup<D>(P, x, alias, a, yq, scratch, kout_all /* wave 0's sorted survivors */, K1 - 1,
-                                            F.len2, t_ids, t_slot, t_gid, t_dist, &cnts[2], F.out_ids, F.out_dist);
+    const u32 cnt2 = stage2_in_workgroup<D, size_t>(P, x, alias, a, yq, scratch, kout_all /* wave 0's sorted survivors */,
+                                                    K1 - 1, F.len2, t_ids, t_slot, t_gid, t_dist, &cnts[2], F.out_ids, F.out_dist);
     if (threadIdx.x == 0) nv_own[x] = cnts[1] + cnt2;  // rows gathered for this query, both stages
   }
   }  // FUSED
