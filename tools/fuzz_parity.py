@@ -7,7 +7,7 @@ backend against the oracle on random shapes and seeds, every result bit for bit.
 Shapes are drawn to hit the different code paths: power-of-two d (register layout + bucket-centric precomp), d with a
 static 3- or 5-lane layout (24, 40, 48, 80, 96, 160), other multiples of the 16-byte chunk, arbitrary d (LDS tree);
 k from 1 to 40 (and occasionally beyond the sorted prefix); tries 1..12; duplicated points (ties) now and then.
-Exit status 1 on the first mismatch, with the case printed so that it can be replayed (--only).
+Every mismatch is printed with its case (shape, seed, rotations) so that it can be replayed; exit status 1 if there was one.
 """
 import argparse
 import os
