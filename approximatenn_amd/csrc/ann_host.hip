@@ -1479,10 +1479,11 @@ extern "C" void annhip_precomp_hash(annhip_precomp *h, int t, size_t row_lo, siz
   X.d = (int)d, X.d_max = (int)d_max, X.ds = (int)ds, X.l = ann_lg(d_max);
   const int wpb = 4;
   const size_t rows = row_hi - row_lo;
-  size_t smem = sizeof(FT) * wpb * (d + d_max + ds);
+  size_t smem = sizeof(FT) * wpb * ANN_HASH_ROWS * (d + d_max + ds);
   if (rows) {
+    const size_t per_wg = (size_t)wpb * ANN_HASH_ROWS;
     allow_lds(hash_rows_kernel, smem);
-    hipLaunchKernelGGL(hash_rows_kernel, dim3((unsigned)((rows + wpb - 1) / wpb)), dim3(64 * wpb), smem, s, X, rows,
+    hipLaunchKernelGGL(hash_rows_kernel, dim3((unsigned)((rows + per_wg - 1) / per_wg)), dim3(64 * wpb), smem, s, X, rows,
                        h->centred + row_lo * d, codes_dev);
     HIPCHECK(hipGetLastError());
   }

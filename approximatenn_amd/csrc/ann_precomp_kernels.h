@@ -97,37 +97,94 @@ __device__ inline void fwht_lds(FT *a, int l) {
   }
 }
 
-// run_initial for one row per wave: code[x] = sign hash of the row's ds low coordinates.
+// run_initial: code[x] = sign hash of the row's ds low coordinates.  Every wave takes ANN_HASH_ROWS consecutive rows
+// and walks them through the chain TOGETHER: each step (a rotation, the permutation, one FWHT level ...) is applied to
+// all of its rows before the wave-level LDS fence, so the ~20 dependent LDS round trips of the chain are paid once per
+// ANN_HASH_ROWS rows instead of once per row (one row per wave: 8.1 ms per try at cfg3, LDS-latency-bound).
+#ifndef ANN_HASH_ROWS
+#define ANN_HASH_ROWS 4
+#endif
+__device__ __forceinline__ void givens_rows(FT *base, size_t stride, int rows, const u32 *ci, const u32 *cj, const FT *cs,
+                                            const FT *sn, int len) {
+  for (int e = lane_id(); e < len * rows; e += ANN_WAVE) {
+    const int r = e / len, y = e - r * len;
+    FT *row = base + (size_t)r * stride;
+    const u32 k = ci[y], l = cj[y];
+    const FT c = cs[y], s = sn[y];
+    const FT vk = row[k], vl = row[l];
+    const FT q = vk * c - vl * s;
+    const FT rr = vk * s + vl * c;
+    row[k] = q;
+    row[l] = rr;
+  }
+  wave_lds_sync();
+}
+
 __global__ __launch_bounds__(256) void hash_rows_kernel(XformDev X, size_t n, const FT *__restrict__ centred,
                                                         u32 *__restrict__ codes) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int R = ANN_HASH_ROWS;
   const int lane = lane_id(), w = threadIdx.x >> 6, wpb = blockDim.x >> 6;
-  const size_t x = (size_t)blockIdx.x * wpb + w;
-  if (x >= n) return;  // whole wave leaves together
-  FT *work = reinterpret_cast<FT *>(smem) + (size_t)w * (X.d + X.d_max + X.ds);
-  FT *wide = work + X.d, *low = wide + X.d_max;
-  for (int z = lane; z < X.d; z += ANN_WAVE) work[z] = centred[x * X.d + z];
-  wave_lds_sync();
-  for (int r = 0; r < X.rots_b; r++)
-    givens_lds(work, X.b_i + r * X.rlb, X.b_j + r * X.rlb, X.b_c + r * X.rlb, X.b_s + r * X.rlb, X.rlb, false);
-  for (int y = lane; y < X.d_max; y += ANN_WAVE) {  // apply_permutation, compute.cl:77-85
-    u32 src = X.perm_b[y];
-    wide[y] = src < (u32)X.d ? work[src] : (FT)0;
+  const size_t x0 = ((size_t)blockIdx.x * wpb + w) * R;
+  if (x0 >= n) return;  // whole wave leaves together
+  const int rows = (int)min((size_t)R, n - x0);
+  const size_t stride = (size_t)X.d + X.d_max + X.ds;  // per row: work[d] | wide[d_max] | low[ds]
+  FT *base = reinterpret_cast<FT *>(smem) + (size_t)w * R * stride;
+  for (int e = lane; e < rows * X.d; e += ANN_WAVE) {
+    const int r = e / X.d, z = e - r * X.d;
+    base[(size_t)r * stride + z] = centred[(x0 + r) * X.d + z];
   }
   wave_lds_sync();
-  fwht_lds(wide, X.l);
-  for (int r = 0; r < X.rots_a; r++)
-    givens_lds(wide, X.a_i + r * X.rla, X.a_j + r * X.rla, X.a_c + r * X.rla, X.a_s + r * X.rla, X.rla, false);
-  for (int y = lane; y < X.d_max; y += ANN_WAVE) {  // apply_perm_inv, compute.cl:88-96
-    u32 dst = X.perm_ai[y];
-    if (dst < (u32)X.ds) low[dst] = wide[y];
+  for (int t = 0; t < X.rots_b; t++)
+    givens_rows(base, stride, rows, X.b_i + t * X.rlb, X.b_j + t * X.rlb, X.b_c + t * X.rlb, X.b_s + t * X.rlb, X.rlb);
+  for (int e = lane; e < rows * X.d_max; e += ANN_WAVE) {  // apply_permutation, compute.cl:77-85
+    const int r = e / X.d_max, y = e - r * X.d_max;
+    const u32 src = X.perm_b[y];
+    FT *row = base + (size_t)r * stride;
+    row[X.d + y] = src < (u32)X.d ? row[src] : (FT)0;
+  }
+  wave_lds_sync();
+  {  // walsh (alg.c:112-120) + apply_walsh_step (compute.cl:101-122) on wide[]
+    const int half = 1 << (X.l - 1);
+#ifdef USE_FLOAT
+    const FT rsr = (FT)(1.0 / __builtin_sqrt(2.0));
+#else
+    const FT rsr = 1.0 / __builtin_sqrt(2.0);
+#endif
+    for (int step = 0; step < X.l; step++) {
+      const FT div = (FT)(step % 2 + 1);
+      const bool scale = step == 0 && (X.l & 1);
+      for (int e = lane; e < rows * half; e += ANN_WAVE) {
+        const int r = e / half, b = e - r * half;
+        FT *a = base + (size_t)r * stride + X.d;
+        const int hi = (b >> step) << step, lo = b ^ hi;
+        const int ia = hi << 1 | lo, ib = ia | 1 << step;
+        const FT xx = a[ia], yy = a[ib];
+        FT p = (xx + yy) / div, q = (xx - yy) / div;
+        if (scale) p = p * rsr, q = q * rsr;
+        a[ia] = p;
+        a[ib] = q;
+      }
+      wave_lds_sync();
+    }
+  }
+  for (int t = 0; t < X.rots_a; t++)
+    givens_rows(base + X.d, stride, rows, X.a_i + t * X.rla, X.a_j + t * X.rla, X.a_c + t * X.rla, X.a_s + t * X.rla, X.rla);
+  for (int e = lane; e < rows * X.d_max; e += ANN_WAVE) {  // apply_perm_inv, compute.cl:88-96
+    const int r = e / X.d_max, y = e - r * X.d_max;
+    const u32 dst = X.perm_ai[y];
+    FT *row = base + (size_t)r * stride;
+    if (dst < (u32)X.ds) row[X.d + X.d_max + dst] = row[X.d + y];
   }
   wave_lds_sync();
   // compute_signs, compute.cl:223-231: coordinate 0 is the most significant bit (ds <= 32 here)
-  bool neg = lane < X.ds && (ft_bits(low[lane < X.ds ? lane : 0]) >> (sizeof(FT) * 8 - 1));
-  u64 m = __ballot(neg);
-  u32 code = X.ds ? (__brev((u32)m) >> (32 - X.ds)) : 0u;
-  if (lane == 0) codes[x] = code;
+  for (int r = 0; r < rows; r++) {
+    const FT *low = base + (size_t)r * stride + X.d + X.d_max;
+    const bool neg = lane < X.ds && (ft_bits(low[lane < X.ds ? lane : 0]) >> (sizeof(FT) * 8 - 1));
+    const u64 m = __ballot(neg);
+    const u32 code = X.ds ? (__brev((u32)m) >> (32 - X.ds)) : 0u;
+    if (lane == 0) codes[x0 + r] = code;
+  }
 }
 
 // save_vecs for one basis row per wave: bases[row][0..d).
