@@ -182,17 +182,16 @@ def main():
         ix.reshard(shard, lo, hi)
         del points
         torch.cuda.empty_cache()
-        runner = ShardedQuery(ix, dist, lanes=2)   # exchange agreed on by all ranks at start-up (all-to-all, else all-gather)
+        runner = ShardedQuery(ix, dist, lanes=3)   # exchange agreed on by all ranks at start-up (all-to-all, else all-gather)
 
-        def run_steps(ys):                          # two batches in flight: exchanges of i under the gather of i+1
-            pend = None
+        def run_steps(ys):      # up to three batches in flight: the exchanges of batch i run under the gathers of i+1, i+2
+            pend = []           # (two suffice when the exchanges are fast; the third lane absorbs collective latency)
             for y in ys:
-                t = runner.submit(y)
-                if pend is not None:
-                    runner.collect(pend)
-                pend = t
-            if pend is not None:
-                runner.collect(pend)
+                pend.append(runner.submit(y))
+                if len(pend) > 2:
+                    runner.collect(pend.pop(0))
+            while pend:
+                runner.collect(pend.pop(0))
     else:
         ns = max(1, args.streams)
         out_ids = [torch.empty((Q, k), dtype=torch.int64, device=device) for _ in range(ns)]
@@ -272,7 +271,7 @@ def main():
                                           "(randNorm.c:9-21), srandom(%d)" % args.seed) if args.data == "randnorm"
                        else "iid N(0,1), torch.randn on the device, seed %d" % args.seed,
                        "points_sharding": "rows/%d" % world,
-                       "streams": (max(1, args.streams) if not sharded else 2), "d_short": ix.d_short, "L1": ix.L1, "P1": ix.P1,
+                       "streams": (max(1, args.streams) if not sharded else 3), "d_short": ix.d_short, "L1": ix.L1, "P1": ix.P1,
                        "L2": ix.L2, "P2": ix.P2, "sum_par_maxes": ix.sum_pm, "datagen_s": round(datagen_s, 2),
                        "precomp_s": round(precomp_s, 2),
                        "exact_path_queries_per_step": round(st["exact_queries"] / args.steps, 2),
