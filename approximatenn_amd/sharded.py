@@ -66,7 +66,6 @@ class HipEngine:
         self.k, self.T, self.Lc1, self.Lc2, self.P1 = ix.k, ix.tries, ix.Lc1, ix.Lc2, ix.P1
         self.ft = torch.float32 if ix.prec == "f32" else torch.float64
         self.key_words = self.lib.annhip_key_bytes() // 8
-        self.device = None
         self._stream = None  # raw hipStream_t of the lane being enqueued (None = the default stream)
 
     # -- streams: one high-priority HIP stream per in-flight batch, one shared stream for the gathers
