@@ -67,6 +67,7 @@ struct EnvCfg {
   int fuse = -1;      // ANN_HIP_FUSE: -1 unset, 0 never, 1 whenever possible
   int s1_waves = 0;   // ANN_HIP_S1_WAVES: 0 unset
   int tail = -1;      // ANN_HIP_TAIL: 0 = stage 2 as separate rows / network / widen kernels (the classic path, A/B and tests)
+  int s2_threads = 64;  // ANN_HIP_S2_THREADS: workgroup size of the fused stage-2 kernel (64, or 128; cfg3: 64-66 vs 67-68 us)
   int segx = -1;      // ANN_HIP_SEGX: -1 unset (auto: shards of <= 30 % of the rows), 0 never, 1 whenever the shard qualifies
   size_t lds_row_max = 150 * 1024, exact_bytes = (size_t)1 << 30;
   size_t exact_rows = 0;  // ANN_HIP_EXACT_ROWS: rows of the device-driven exact workspace (0 = auto)
@@ -93,6 +94,7 @@ static void load_env() {
   if (c.s1_waves < 1 || c.s1_waves > 4) c.s1_waves = 0;
   c.segx = env_int("ANN_HIP_SEGX", -1);
   c.tail = env_int("ANN_HIP_TAIL", -1);
+  c.s2_threads = env_int("ANN_HIP_S2_THREADS", 64) == 128 ? 128 : 64;
   c.lds_row_max = env_size("ANN_HIP_LDS_ROW_MAX", 150 * 1024);
   c.exact_bytes = env_size("ANN_HIP_EXACT_BYTES", (size_t)1 << 30);
   c.exact_rows = env_size("ANN_HIP_EXACT_ROWS", 0);
@@ -741,7 +743,7 @@ static void launch_stage2_fused(const QParams &P, size_t Q, const FT *y, int ali
 #define CALL(DD)                                                                                                   \
   do {                                                                                                             \
     allow_lds((stage2_fused_kernel<DD, IdOut>), smem);                                                             \
-    hipLaunchKernelGGL((stage2_fused_kernel<DD, IdOut>), dim3((unsigned)nq), dim3(128), smem, s, P, (int)Q, y, alias, \
+    hipLaunchKernelGGL((stage2_fused_kernel<DD, IdOut>), dim3((unsigned)nq), dim3(env().s2_threads), smem, s, P, (int)Q, y, alias, \
                        top_i, top_d, P.Lc2, out_ids, out_d, rows_ctr, xbase);                                      \
   } while (0)
   ANN_DISPATCH_D(P.d, CALL);
