@@ -91,10 +91,8 @@ class HipEngine:
             self._stream = prev
             self.lib.annhip_index_set_stream(self.h, prev)
 
-    def event(self, stream):
-        ev = torch.cuda.Event()
-        ev.record(stream)
-        return ev
+    def new_event(self):
+        return torch.cuda.Event()
 
     def empty(self, shape, dtype, like):
         return torch.empty(shape, dtype=dtype, device=like.device)
@@ -103,8 +101,10 @@ class HipEngine:
     def sh_codes(self, y, q_lo, q_hi, out):
         self.lib.annhip_sh_codes(self.h, self._stream, y.shape[0], y.data_ptr(), q_lo, q_hi, out.data_ptr())
 
-    def sh_stage1(self, y, alias, codes, keys, nvalid, nown):
-        self.lib.annhip_sh_stage1(self.h, self._stream, y.shape[0], y.data_ptr(), int(alias), codes.data_ptr(),
+    def sh_stage1(self, y, alias, codes, keys, nvalid, nown, stream=None):
+        """stream: launch there instead of on the lane's stream (the shared gather stream)."""
+        s = stream.cuda_stream if stream is not None else self._stream
+        self.lib.annhip_sh_stage1(self.h, s, y.shape[0], y.data_ptr(), int(alias), codes.data_ptr(),
                                   keys.data_ptr(), nvalid.data_ptr(), nown.data_ptr())
 
     def sh_merge_finalize(self, G, Q, q_lo, qs, keys_in, nvalid, top_i, top_d):
@@ -154,6 +154,7 @@ class _Lane:
 
     def __init__(self, stream):
         self.stream, self.shape, self.busy, self.event, self.need_back = stream, None, False, None, False
+        self.ev_in = self.ev_out = None
 
     def ensure(self, eng, y, G, qs, fcap):
         Q = y.shape[0]
@@ -307,12 +308,15 @@ class ShardedQuery:
             self._gather_cat(L.codes_all, L.codes_slice)
             if not self.exact_all:
                 gs = self._gather_stream if L.stream is not None else None
+                if gs is not None:                                       # gathers of all batches: back to back
+                    if L.ev_in is None:
+                        L.ev_in, L.ev_out, L.event = e.new_event(), e.new_event(), e.new_event()
+                    L.ev_in.record(L.stream)
+                    gs.wait_event(L.ev_in)
+                e.sh_stage1(y, alias, L.codes_all, L.keys, L.nvalid, L.nown, stream=gs)
                 if gs is not None:
-                    gs.wait_event(e.event(L.stream))
-                with e.use(gs):                                          # gathers of all batches: back to back
-                    e.sh_stage1(y, alias, L.codes_all, L.keys, L.nvalid, L.nown)
-                if gs is not None:
-                    L.stream.wait_event(e.event(gs))
+                    L.ev_out.record(gs)
+                    L.stream.wait_event(L.ev_out)
         L.busy, L.need_back = True, True
         for P in self._lanes:                                            # the batch submitted before this one
             if P is not L and P.busy and P.need_back:
@@ -346,7 +350,8 @@ class ShardedQuery:
             L.head_dev[1:2].copy_(L.flist[1:2])
             L.head_host.copy_(L.head_dev, non_blocking=True)
             if L.stream is not None:
-                L.event = torch.cuda.Event()
+                if L.event is None:
+                    L.event = e.new_event()
                 L.event.record(L.stream)
         L.need_back = False
 

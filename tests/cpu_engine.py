@@ -92,7 +92,7 @@ class CpuShardEngine:
         if hi > q_lo:
             out.numpy().view(np.uint32)[: (hi - q_lo) * self.T] = c[q_lo * self.T: hi * self.T]
 
-    def sh_stage1(self, y, alias, codes, keys, nvalid, nown):
+    def sh_stage1(self, y, alias, codes, keys, nvalid, nown, stream=None):
         Q, K1, kw = y.shape[0], self.k + 1, self.key_words
         cd, ci, nv = self.stage1_local(y, alias, codes)
         cdn, cin = cd.numpy(), ci.numpy().view(np.uint32)
