@@ -42,7 +42,7 @@ def test_save_t_layout_matches_reference_abi():
 @pytest.mark.parametrize("prec", ["f32", "f64"])
 def test_synth_randnorm_is_the_reference_drivers_stream(prec):
     """annhip_synth_randnorm (host-only, threads for the libm part) against the oracle's serial generator -- which is
-    pinned to the reference's rand_norm/genRand (tests/test_oracle_vs_ref.py): same values bit for bit, same number of
+    pinned to the reference's rand_norm/genRand by the golden point sets (tests/test_oracle_golden.py): same values bit for bit, same number of
     random() draws, the pending second value of an odd-length call carried into the next call."""
     import numpy as np
 
