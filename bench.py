@@ -282,6 +282,10 @@ def main():
     if runner is not None:
         line["config"]["exchange"] = runner.exchange
         line["config"]["queries_per_step_total"] = Q
+        line["config"]["batches_in_flight"] = 3
+        line["config"]["note"] = ("steps are pipelined (up to 3 batches in flight, all K steps complete inside the timed "
+                                  "region); the like-for-like single-GPU figure is the N=1 line's `overlap.value` (2 batches "
+                                  "in flight), its `value` is strictly serial")
 
     # ---- N > 1 extra: strong scaling -- the batch FIXED at --queries in total (10k), sharded the same way
     if sharded and not args.no_strong_extra:
