@@ -26,6 +26,16 @@ def bits_equal(a, b):
     return a.shape == b.shape and np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8))
 
 
+def draw_big_case(rng):
+    """Larger shapes (d_short 11..14, thousands of candidates per row, batches of thousands): the sizes at which the
+    production paths (bucket-centric precomp, multi-wave stage 1, fused stage 2) run with realistic occupancy."""
+    d = rng.choice([64, 128, 80, 32, 256])
+    k = rng.choice([5, 10, 10, 20, 50])
+    n = rng.choice([20000, 30000, 50000])
+    return dict(kind="big", n=n, d=d, k=k, T=rng.choice([4, 7, 10]), Q=rng.choice([1000, 3000]), dup=rng.random() < 0.1,
+                seed=rng.randrange(1, 1 << 30), rb=6, rlb=1, ra=1, rla=1)
+
+
 def draw_case(rng):
     kind = rng.choice(["pow2", "pow2", "static_oc", "static_oc", "chunks", "any"])
     if kind == "pow2":
@@ -108,17 +118,18 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--prec", default="f32,f64")
     ap.add_argument("--sharded", action="store_true")
+    ap.add_argument("--big", action="store_true", help="larger shapes (slow: the oracle is the bottleneck)")
     a = ap.parse_args()
     rng = random.Random(a.seed)
     bad = 0
     for i in range(a.cases):
-        c = draw_case(rng)
+        c = draw_big_case(rng) if a.big else draw_case(rng)
         for prec in a.prec.split(","):
             err = run_case(dict(c), prec, a.sharded)
             if err:
                 bad += 1
                 print("MISMATCH (%s) %s %r" % (err, prec, c), flush=True)
-        if (i + 1) % 10 == 0:
+        if (i + 1) % (2 if a.big else 10) == 0:
             print("%d cases done, %d mismatches" % (i + 1, bad), flush=True)
     print("fuzz: %d cases x %s, %d mismatches" % (a.cases, a.prec, bad))
     sys.exit(1 if bad else 0)
