@@ -413,7 +413,8 @@ def precomp_sharded(points, k, tries=10, rots_before=6, rot_len_before=1, rots_a
     prec = "f32" if points.dtype == torch.float32 else "f64"
     lib = _lib.load(prec)
     assert points.is_cuda and points.is_contiguous()
-    on = dist is not None and dist.is_initialized() and dist.get_world_size(group) > 1
+    on = dist is not None and dist.is_initialized() and (dist.get_world_size(group) > 1 or
+                                                         os.environ.get("ANN_SHARD_FORCE_DIST") == "1")
     world = dist.get_world_size(group) if on else 1
     rank = dist.get_rank(group) if on else 0
     via_cpu = on and dist.get_backend(group) == "gloo"
