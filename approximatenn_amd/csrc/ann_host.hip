@@ -245,6 +245,7 @@ struct annhip_index {
   double seg_ms[6] = {0, 0, 0, 0, 0, 0};          // codes, stage1, finalize+fallback, stage-2 rows, stage-2 network, widen
   double s1_ms = 0;
   double s1_launches = 0, queries = 0;
+  int gather_pieces = 1;  // annhip_sh_stage1 in this many launches (annhip_index_set_gather_pieces)
 };
 
 static QParams make_params(const annhip_index *ix) {
@@ -257,6 +258,7 @@ static QParams make_params(const annhip_index *ix) {
   P.n = (u32)ix->n, P.lo = (u32)ix->lo, P.hi = (u32)ix->hi;
   P.d = (int)ix->d, P.k = (int)ix->k, P.T = ix->T, P.ds = (int)ix->ds;
   P.L1 = ix->L1, P.P1 = ix->P1, P.Lc1 = ix->Lc1, P.L2 = ix->L2, P.Lc2 = ix->Lc2;
+  P.q0 = 0;
   return P;
 }
 
@@ -339,6 +341,7 @@ static void check_limits(size_t n, size_t k, size_t d, size_t ds, int T) {
 }
 
 extern "C" void annhip_index_set_stream(annhip_index *ix, void *s) { ix->stream = (hipStream_t)s; }
+extern "C" void annhip_index_set_gather_pieces(annhip_index *ix, int pieces) { ix->gather_pieces = pieces < 1 ? 1 : pieces; }
 
 extern "C" annhip_index *annhip_index_create(const save_t *save, const ftype *points, int on_device,
                                              size_t row_lo, size_t row_hi) {
@@ -592,7 +595,7 @@ __global__ void sum_u32_kernel(size_t count, const u32 *__restrict__ v, unsigned
 static void launch_stage1(annhip_index *ix, const QParams &P, size_t Q, const FT *y, int alias,
                           const u32 *codes, FT *cand_d, u32 *cand_i, u32 *nvt, u32 *nvo, hipStream_t s,
                           const std::vector<TryInfo> &h_tries, int use_seg, FusedTail F = FusedTail{0, 0, NULL, NULL, NULL, NULL, NULL},
-                          Key *cand_key = NULL) {
+                          Key *cand_key = NULL, int pieces = 1) {
   if (!Q) return;
   const int K1 = P.k + 1, W = stage1_waves(P.P1, (double)(P.hi - P.lo) / (double)P.n), cap = stage1_cap(W, K1);
   const size_t smem = stage1_lds_bytes(P, W, K1, cap, F.enabled ? F.len2 : 0);
@@ -617,8 +620,13 @@ static void launch_stage1(annhip_index *ix, const QParams &P, size_t Q, const FT
 #define CALL_V(DD, SG, FU)                                                                                   \
   do {                                                                                                       \
     allow_lds(stage1_select_kernel<DD, SG, FU>, smem);                                                       \
-    hipLaunchKernelGGL((stage1_select_kernel<DD, SG, FU>), dim3((unsigned)Q), dim3(64 * W), smem, s, P, (int)Q, y, \
-                       alias, codes, K1, cap, runs_used, cand_d, cand_i, nvt, nvo, F, cand_key);             \
+    const size_t np = (size_t)std::max(1, std::min(pieces, 64)), per = (Q + np - 1) / np;                    \
+    for (size_t a = 0; a < Q; a += per) {                                                                    \
+      QParams Pp = P;                                                                                        \
+      Pp.q0 = (u32)a;                                                                                        \
+      hipLaunchKernelGGL((stage1_select_kernel<DD, SG, FU>), dim3((unsigned)std::min(per, Q - a)), dim3(64 * W), smem, s, \
+                         Pp, (int)Q, y, alias, codes, K1, cap, runs_used, cand_d, cand_i, nvt, nvo, F, cand_key); \
+    }                                                                                                        \
   } while (0)
 #define CALL(DD)                                 \
   do {                                           \
@@ -1098,7 +1106,7 @@ extern "C" void annhip_sh_stage1(annhip_index *ix, void *hip_stream, size_t Q, c
   if ((u32)P.k > P.P1) die("annhip_sh_stage1: k exceeds the sorted prefix; use the exact path (annhip_stage1_rows)");
   launch_stage1(ix, P, Q, reinterpret_cast<const FT *>(y_dev), alias, codes_dev, NULL, NULL, nvalid_dev, nown_dev,
                 (hipStream_t)hip_stream, ix->h_tries, ix->use_seg, FusedTail{0, 0, NULL, NULL, NULL, NULL, NULL},
-                reinterpret_cast<Key *>(keys_dev));
+                reinterpret_cast<Key *>(keys_dev), ix->gather_pieces);
   ix->queries += (double)Q;
 }
 

@@ -41,6 +41,7 @@ struct QParams {
   u32 n, lo, hi;
   int d, k, T, ds;
   u32 L1, P1, Lc1, L2, Lc2;
+  u32 q0;            // stage 1 launched in pieces: the first query of this launch
 };
 
 #define ANN_S1_CHUNK 1024  // slots whose valid ids one wave stages in LDS at a time
@@ -524,7 +525,7 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
                                                             Key *__restrict__ cand_key) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = lane_id(), w = threadIdx.x >> 6, W = blockDim.x >> 6;
-  const u32 x = blockIdx.x;
+  const u32 x = blockIdx.x + P.q0;
   // ---- LDS carve-up (mirrored by stage1_lds_bytes on the host)
   unsigned char *sp = smem;
   Key *kbuf_all = reinterpret_cast<Key *>(sp);           sp += sizeof(Key) * (size_t)W * cap;

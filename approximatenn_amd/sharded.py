@@ -94,6 +94,9 @@ class HipEngine:
     def new_event(self):
         return torch.cuda.Event()
 
+    def set_gather_pieces(self, pieces):
+        self.lib.annhip_index_set_gather_pieces(self.h, int(pieces))
+
     def empty(self, shape, dtype, like):
         return torch.empty(shape, dtype=dtype, device=like.device)
 
@@ -211,8 +214,11 @@ class ShardedQuery:
         self.fcap = max(1, int(fcap))
         # compute units the gathers leave to everything else (small kernels, RCCL); ANN_SHARD_RESERVE_CUS overrides
         self.reserve_cus = int(os.environ.get("ANN_SHARD_RESERVE_CUS", 0 if reserve_cus is None else reserve_cus))
-        self._gather_stream = None
+        self._gather_streams = {}           # CUs left free -> the gathers' stream
         self._lanes = [_Lane(None) for _ in range(max(1, lanes))]
+        self.depth = len(self._lanes)       # lanes in use (autotune() may lower it)
+        self.split = os.environ.get("ANN_SHARD_NO_SPLIT") != "1"   # issue a batch in two halves (see submit())
+        self.tuned, self.pieces = None, 1
         self._next, self._tickets = 0, {}
         self.last_exact = 0
 
@@ -290,13 +296,13 @@ class ShardedQuery:
     def submit(self, y, alias=False):
         """Enqueue one batch (y: [Q,d], identical on every rank).  Returns a ticket for collect()."""
         e, G, r = self.eng, self.world, self.rank
-        L = self._lanes[self._next % len(self._lanes)]
+        L = self._lanes[self._next % self.depth]
         if L.busy:
             raise RuntimeError("every lane is in flight: collect() the oldest ticket first")
         if L.stream is None and y.is_cuda:
             L.stream = e.new_stream(y.device, high_priority=True)
-            if self._gather_stream is None:
-                self._gather_stream = e.new_stream(y.device, reserve_cus=self.reserve_cus)
+        if y.is_cuda and self.reserve_cus not in self._gather_streams:
+            self._gather_streams[self.reserve_cus] = e.new_stream(y.device, reserve_cus=self.reserve_cus)
         Q = y.shape[0]
         L.y, L.alias, L.Q, L.qs = y, alias, Q, (Q + G - 1) // G
         L.q_lo = r * L.qs
@@ -307,7 +313,7 @@ class ShardedQuery:
             e.sh_codes(y, L.q_lo, L.q_lo + L.qs, L.codes_slice)
             self._gather_cat(L.codes_all, L.codes_slice)
             if not self.exact_all:
-                gs = self._gather_stream if L.stream is not None else None
+                gs = self._gather_streams[self.reserve_cus] if L.stream is not None else None
                 if gs is not None:                                       # gathers of all batches: back to back
                     if L.ev_in is None:
                         L.ev_in, L.ev_out, L.event = e.new_event(), e.new_event(), e.new_event()
@@ -318,6 +324,8 @@ class ShardedQuery:
                     L.ev_out.record(gs)
                     L.stream.wait_event(L.ev_out)
         L.busy, L.need_back = True, True
+        if not self.split:                                               # the whole batch at once
+            self._back(L)
         for P in self._lanes:                                            # the batch submitted before this one
             if P is not L and P.busy and P.need_back:
                 self._back(P)
@@ -393,6 +401,67 @@ class ShardedQuery:
     def query(self, y, alias=False):
         """y: [Q,d] (identical on every rank).  Returns (ids int64 [Q,k], squared distances [Q,k])."""
         return self.collect(self.submit(y, alias))
+
+    # ------------------------------------------------------------------ scheduling knobs, measured in place
+    # How the small kernels and the RCCL kernels of one batch get compute units beside the saturating gather of the next
+    # one depends on the machine state (ranks, RCCL channel count, batch size): nothing of it changes a result bit, so it
+    # is measured, not guessed.
+    # Candidates: (lanes in use, two-half issue, CUs the gathers leave free, launches per gather).
+    TUNE_CANDIDATES = ((3, True, 0, 1), (3, False, 0, 1), (2, False, 0, 1), (3, True, 0, 4), (3, False, 0, 4), (2, False, 0, 4),
+                       (3, True, 0, 8), (3, False, 0, 8), (3, True, 8, 1), (3, False, 8, 1), (2, False, 8, 1), (3, False, 8, 4),
+                       (1, False, 0, 1))
+
+    def pump(self, ys, alias=False):
+        """Pipelined loop over the batches ys with `depth` batches in flight; returns the list of results."""
+        out, pend = [], []
+        for y in ys:
+            pend.append(self.submit(y, alias))
+            if len(pend) >= self.depth:
+                out.append(self.collect(pend.pop(0)))
+        while pend:
+            out.append(self.collect(pend.pop(0)))
+        return out
+
+    def configure(self, depth, split, reserve_cus=0, pieces=1):
+        if any(L.busy for L in self._lanes):
+            raise RuntimeError("configure() with batches in flight")
+        self.depth, self.split, self.reserve_cus = max(1, min(int(depth), len(self._lanes))), bool(split), int(reserve_cus)
+        self.pieces = max(1, int(pieces))
+        self.eng.set_gather_pieces(self.pieces)
+
+    def autotune(self, y, alias=False, batches=8, candidates=None):
+        """Time `batches` pipelined batches of y under each candidate setting (after 3 untimed ones), take the MAX over
+        the ranks of each time, keep the fastest: every rank ends with the same setting, which the collectives' issue
+        order requires.  Returns {"depth", "split", "reserve_cus", "pieces", "ms_per_batch", "table"}; also kept in self.tuned."""
+        import time
+        cands = [c for c in (candidates or self.TUNE_CANDIDATES) if c[0] <= len(self._lanes)]
+        sync = (lambda: torch.cuda.synchronize(y.device)) if y.is_cuda else (lambda: None)
+        table = []
+        self.configure(len(self._lanes), True, 0, 1)
+        self.pump([y] * (len(self._lanes) + 1), alias)        # every lane's buffers and streams exist before anything is timed
+        for c in cands:
+            self.configure(*c)
+            self.pump([y] * 3, alias)
+            sync()
+            if self.dist:
+                self.dist.barrier(group=self.group)
+            t0 = time.perf_counter()
+            self.pump([y] * batches, alias)
+            sync()
+            table.append((time.perf_counter() - t0) * 1e3 / batches)
+        t = torch.tensor(table, dtype=torch.float64)
+        if self.dist:
+            dev = "cpu" if (self._via_cpu or not y.is_cuda) else y.device
+            t = -t.to(dev)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)     # = MAX of the times
+            t = -t.cpu()
+        best = int(torch.argmin(t))
+        self.configure(*cands[best])
+        self.tuned = {"depth": self.depth, "split": self.split, "reserve_cus": self.reserve_cus, "pieces": self.pieces,
+                      "ms_per_batch": round(float(t[best]), 4),
+                      "table": [{"depth": c[0], "split": c[1], "reserve_cus": c[2], "pieces": c[3], "ms": round(float(v), 4)}
+                                for c, v in zip(cands, t.tolist())]}
+        return self.tuned
 
 
 def precomp_sharded(points, k, tries=10, rots_before=6, rot_len_before=1, rots_after=1, rot_len_after=1, dist=None,

@@ -183,15 +183,17 @@ def main():
         del points
         torch.cuda.empty_cache()
         runner = ShardedQuery(ix, dist, lanes=3)   # exchange agreed on by all ranks at start-up (all-to-all, else all-gather)
+        # up to three batches in flight: the exchanges of batch i run under the gathers of i+1, i+2.  How many lanes, the
+        # issue order and the CUs kept free for RCCL's kernels are measured here, before the warm-up (a few dozen untimed
+        # batches, same on every rank; no result bit depends on them).  ANN_SHARD_TUNE=depth,split,reserve,pieces pins them.
+        pin = os.environ.get("ANN_SHARD_TUNE")
+        if pin:
+            runner.configure(*[int(v) for v in pin.split(",")])
+        else:
+            runner.autotune(batches[0])
 
-        def run_steps(ys):      # up to three batches in flight: the exchanges of batch i run under the gathers of i+1, i+2
-            pend = []           # (two suffice when the exchanges are fast; the third lane absorbs collective latency)
-            for y in ys:
-                pend.append(runner.submit(y))
-                if len(pend) > 2:
-                    runner.collect(pend.pop(0))
-            while pend:
-                runner.collect(pend.pop(0))
+        def run_steps(ys):
+            runner.pump(ys)
     else:
         ns = max(1, args.streams)
         out_ids = [torch.empty((Q, k), dtype=torch.int64, device=device) for _ in range(ns)]
@@ -247,7 +249,7 @@ def main():
                 "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
                 "rows_gathered_per_query": round(v1, 1)}
     if sharded:
-        roofline["note"] = "rank 0's kernel; with two batches in flight it overlaps the other batch's small kernels"
+        roofline["note"] = "rank 0's kernel; with several batches in flight it overlaps the other batches's small kernels"
 
     # PMC counters cannot be read in-process: for the default workload the figure is the committed rocprofv3 --pmc
     # measurement of this same command (profiles/traffic.json says which run); any other workload reports null.
@@ -271,7 +273,7 @@ def main():
                                           "(randNorm.c:9-21), srandom(%d)" % args.seed) if args.data == "randnorm"
                        else "iid N(0,1), torch.randn on the device, seed %d" % args.seed,
                        "points_sharding": "rows/%d" % world,
-                       "streams": (max(1, args.streams) if not sharded else 3), "d_short": ix.d_short, "L1": ix.L1, "P1": ix.P1,
+                       "streams": (max(1, args.streams) if not sharded else runner.depth), "d_short": ix.d_short, "L1": ix.L1, "P1": ix.P1,
                        "L2": ix.L2, "P2": ix.P2, "sum_par_maxes": ix.sum_pm, "datagen_s": round(datagen_s, 2),
                        "precomp_s": round(precomp_s, 2),
                        "exact_path_queries_per_step": round(st["exact_queries"] / args.steps, 2),
@@ -282,7 +284,10 @@ def main():
     if runner is not None:
         line["config"]["exchange"] = runner.exchange
         line["config"]["queries_per_step_total"] = Q
-        line["config"]["batches_in_flight"] = 3
+        line["config"]["batches_in_flight"] = runner.depth
+        line["config"]["schedule"] = runner.tuned or {"depth": runner.depth, "split": runner.split,
+                                                      "reserve_cus": runner.reserve_cus, "pieces": runner.pieces,
+                                                      "pinned": True}
         line["config"]["note"] = ("steps are pipelined (up to 3 batches in flight, all K steps complete inside the timed "
                                   "region); the like-for-like single-GPU figure is the N=1 line's `overlap.value` (2 batches "
                                   "in flight), its `value` is strictly serial")
@@ -291,10 +296,13 @@ def main():
     if sharded and not args.no_strong_extra:
         Qs = args.q
         ys = [b[:Qs].contiguous() for b in batches]
+        if not pin:
+            runner.autotune(ys[0])          # a batch this small wants its own schedule
         run_steps(ys[:args.warmup])
         el_s, _ = timed(ys[args.warmup:])
         line["strong"] = {"queries_per_step_total": Qs, "value": round(Qs * args.steps / el_s, 1), "unit": "queries/s",
                           "ms_per_step": round(el_s / args.steps * 1e3, 4),
+                          "schedule": {k_: v for k_, v in (runner.tuned or {}).items() if k_ != "table"},
                           "note": "same job with the batch fixed at %d queries in total (results differ from the weak "
                                   "run's: they depend on the batch, SURVEY Q2)" % Qs}
 

@@ -33,6 +33,9 @@ void annhip_index_destroy(annhip_index *ix);
 void annhip_index_info(const annhip_index *ix, size_t out[12]);
 /* All launches of this index go to `hip_stream` (a hipStream_t; NULL = the default stream). */
 void annhip_index_set_stream(annhip_index *ix, void *hip_stream);
+/* annhip_sh_stage1 launches its gather in `pieces` kernels over consecutive query ranges (default 1).  Same results;
+ * the launch boundaries are where workgroups of other streams -- RCCL's in particular -- find free compute units. */
+void annhip_index_set_gather_pieces(annhip_index *ix, int pieces);
 /* Point-shard an index that was built from all n rows: from now on this device owns rows [row_lo,row_hi) only
  * and reads them from shard_points_dev (device pointer to those rows, borrowed).  Tables and graph stay. */
 void annhip_index_reshard(annhip_index *ix, const ftype *shard_points_dev, size_t row_lo, size_t row_hi);

@@ -78,6 +78,9 @@ class CpuShardEngine:
     def use(self, stream):
         return contextlib.nullcontext()
 
+    def set_gather_pieces(self, pieces):      # a launch-shape knob of the device engine: nothing to do here
+        pass
+
     def empty(self, shape, dtype, like):
         return torch.empty(shape, dtype=dtype)
 

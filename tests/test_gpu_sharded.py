@@ -67,7 +67,7 @@ class ThreadDist:
         self._done()
 
 
-def _run_sharded(prec, save_arrays, pts, y, world, alias=False, fast=True, pipelined=False):
+def _run_sharded(prec, save_arrays, pts, y, world, alias=False, fast=True, pipelined=False, schedule=None):
     save = A.Save.from_dict(prec, save_arrays)
     td = ThreadDist(world)
     results, errors = [None] * world, []
@@ -78,8 +78,14 @@ def _run_sharded(prec, save_arrays, pts, y, world, alias=False, fast=True, pipel
             td.tl.rank = rank
             lo, hi = (len(pts) * rank) // world, (len(pts) * (rank + 1)) // world
             ix = A.Index.from_save(save, torch.from_numpy(np.ascontiguousarray(pts[lo:hi])).cuda(), lo, hi)
-            sq = ShardedQuery(ix, td, exchange="alltoall" if fast else "allgather")
-            if pipelined:    # two batches in flight on two HIP streams
+            sq = ShardedQuery(ix, td, exchange="alltoall" if fast else "allgather", lanes=3 if schedule else 2)
+            if schedule:     # (lanes in use, two-half issue, CUs kept free of the gathers, launches per gather)
+                sq.configure(*schedule)
+                res = sq.pump([yt] * 5, alias=alias)
+                ids, dd = res[0]
+                for ids1, dd1 in res[1:]:
+                    assert torch.equal(ids, ids1) and torch.equal(dd.view(torch.uint8), dd1.view(torch.uint8))
+            elif pipelined:  # two batches in flight on two HIP streams
                 t0, t1 = sq.submit(yt, alias=alias), sq.submit(yt, alias=alias)
                 ids, dd = sq.collect(t0)
                 ids1, dd1 = sq.collect(t1)
@@ -156,6 +162,14 @@ def test_sharded_alias_query():
 def test_two_batches_in_flight(name, world):
     g = load_golden(name)
     for ids, dd, _ in _run_sharded(g["prec"], g["save"], g["points"], g["y"], world, pipelined=True):
+        assert np.array_equal(ids, g["query_ids"]) and bits_equal(dd, g["query_dists"])
+
+
+@pytest.mark.parametrize("schedule", [(3, True, 0, 4), (2, False, 8, 3), (1, False, 0, 7), (3, False, 0, 1)])
+def test_schedules_do_not_change_results(schedule):
+    # what ShardedQuery.autotune() chooses between: lanes, issue order, a CU-masked gather stream, the gather in pieces
+    g = load_golden("pow2_d128_f32")
+    for ids, dd, _ in _run_sharded(g["prec"], g["save"], g["points"], g["y"], 2, schedule=schedule):
         assert np.array_equal(ids, g["query_ids"]) and bits_equal(dd, g["query_dists"])
 
 

@@ -85,6 +85,19 @@ def _worker_modes(rank, world, case, mode):
             sq.submit(yt), sq.submit(yt)          # only two lanes
         ids, dd = sq.collect(t0)
         sq.collect(t0 + 1)
+    elif mode == "autotune":     # the schedule is measured and agreed on (MAX over ranks per candidate); results unchanged
+        sq = ShardedQuery(eng, dist, lanes=3)
+        tuned = sq.autotune(yt, batches=2, candidates=[(3, True, 0, 1), (2, False, 0, 4), (1, False, 0, 1)])
+        assert len(tuned["table"]) == 3 and (tuned["depth"], tuned["split"], tuned["pieces"]) in [(3, True, 1), (2, False, 4), (1, False, 1)]
+        mine = torch.tensor([tuned["depth"], int(tuned["split"]), tuned["pieces"]], dtype=torch.int64)
+        lo_, hi_ = mine.clone(), mine.clone()
+        dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+        assert torch.equal(lo_, hi_), "ranks disagree on the schedule"
+        res = sq.pump([yt, yt, yt, yt])
+        assert len(res) == 4
+        for ids, dd in res:
+            assert np.array_equal(ids.numpy().astype(np.uint64), want_ids) and bits_equal(dd.numpy(), want_d)
     else:
         raise AssertionError(mode)
     assert np.array_equal(ids.numpy().astype(np.uint64), want_ids), "rank %d ids (%s)" % (rank, mode)
@@ -92,7 +105,7 @@ def _worker_modes(rank, world, case, mode):
 
 
 @pytest.mark.parametrize("world,case,mode", [(2, "tiny_appendixA_f32", "allgather"), (3, "few_candidates_f64", "allgather"),
-                                             (2, "odd_everything_f32", "exact"), (3, "tiny_appendixA_f32", "pipelined")])
+                                             (2, "odd_everything_f32", "exact"), (3, "tiny_appendixA_f32", "pipelined"), (2, "tiny_appendixA_f32", "autotune")])
 def test_sharded_query_modes(world, case, mode):
     port = 29500 + (os.getpid() + hash((case, mode))) % 2000
     mp.spawn(_worker, args=(world, port, case, mode), nprocs=world, join=True)

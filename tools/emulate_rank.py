@@ -6,7 +6,12 @@ padding / copies), so RESULTS ARE MEANINGLESS and communication time is NOT incl
 and the host-side orchestration are representative.  Used to project scaling before a multi-GPU node is available
 (DESIGN.md section 4).
 
-    python tools/emulate_rank.py [--points N] [--queries Q_per_rank]
+    python tools/emulate_rank.py [--points N] [--queries Q_per_rank] [--rccl] [--tune]
+
+--rccl: every stand-in collective additionally pushes its payload through a real RCCL kernel (a one-rank NCCL process
+group's all_to_all_single on the communicator's own stream), so that the placement of RCCL's workgroups beside the
+saturating gather -- and the stream hand-offs around them -- are part of what is timed.  --tune: print
+ShardedQuery.autotune()'s table (lanes in use, two-half issue, CUs the gathers leave free) for each world size.
 """
 import argparse
 import ctypes
@@ -26,7 +31,18 @@ ap.add_argument("--queries", type=int, default=10_000)
 ap.add_argument("--worlds", type=str, default="1,2,4,8")
 ap.add_argument("--lanes", type=int, default=3)
 ap.add_argument("--steps", type=int, default=12)
+ap.add_argument("--rccl", action="store_true")
+ap.add_argument("--tune", action="store_true")
 args = ap.parse_args()
+
+real = None
+if args.rccl:
+    import torch.distributed as real
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29655")
+    torch.cuda.set_device(0)
+    opts = real.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+    real.init_process_group("nccl", rank=0, world_size=1, pg_options=opts, device_id=torch.device("cuda", 0))
 
 
 class Loopback:
@@ -37,6 +53,18 @@ class Loopback:
 
     def __init__(self, world):
         self.world = world
+        self._scratch = {}
+
+    def _kernel(self, t):
+        """The payload once through an RCCL kernel (one-rank all-to-all = a copy done by rcclGenericKernel)."""
+        if real is None:
+            return
+        key = (t.numel() * t.element_size())
+        if key not in self._scratch:
+            self._scratch[key] = torch.empty(key, dtype=torch.uint8, device=t.device)
+        real.all_to_all_single(self._scratch[key], t.contiguous().view(torch.uint8).view(-1))
+
+    def barrier(self, group=None): pass
 
     def is_initialized(self): return True
     def get_world_size(self, g=None): return self.world
@@ -44,9 +72,11 @@ class Loopback:
     def get_backend(self, g=None): return "loopback"
 
     def all_gather_into_tensor(self, out, t, group=None):   # every rank "contributed" what this one did
+        self._kernel(t)
         out.view(self.world, -1).copy_(t.reshape(1, -1).expand(self.world, -1))
 
     def all_to_all_single(self, out, t, group=None):        # own part arrives; the peers' parts are padding
+        self._kernel(t)
         n = t.shape[0] // self.world
         if t.dtype == torch.int64:
             out.fill_((0x7F800000 << 32) | 0xFFFFFFFF)       # key(+inf, no id) of the float build
@@ -54,7 +84,9 @@ class Loopback:
             out.fill_(float("inf"))
         out[:n].copy_(t[:n])
 
-    def all_reduce(self, t, op=None, group=None): pass
+    def all_reduce(self, t, op=None, group=None):
+        if t.is_cuda:
+            self._kernel(t)
 
 
 n, d, k, T = args.points, 128, 10, 10
@@ -77,13 +109,20 @@ for G in [int(g) for g in args.worlds.split(",")]:
         lo, hi = 0, n // G
         ix.reshard(points[lo:hi], lo, hi)
         sq = ShardedQuery(ix, Loopback(G), exchange="alltoall", lanes=args.lanes)
+        lanes_used = args.lanes
 
+        if args.tune:
+            tuned = sq.autotune(ys[0], batches=10)
+            for row in tuned["table"]:
+                print("   tune G=%d: lanes %d  split %d  reserve %2d CUs  gather in %d -> %.3f ms/batch" %
+                      (G, row["depth"], row["split"], row["reserve_cus"], row["pieces"], row["ms"]), flush=True)
+            lanes_used = sq.depth
         host = {"submit": 0.0, "collect": 0.0, "n": 0}
 
         def run_all(batches):     # several batches in flight, as bench.py --gpus N drives it
             pend = []
             for y in batches:
-                if len(pend) == args.lanes:
+                if len(pend) == lanes_used:
                     t0 = time.perf_counter()
                     sq.collect(pend.pop(0))
                     host["collect"] += time.perf_counter() - t0
@@ -93,7 +132,7 @@ for G in [int(g) for g in args.worlds.split(",")]:
                 host["n"] += 1
             while pend:
                 sq.collect(pend.pop(0))
-        label = "submit/collect, %d lanes" % args.lanes
+        label = "submit/collect, %d lanes" % lanes_used
     run_all(ys[:4])
     torch.cuda.synchronize()
     if G > 1:
