@@ -759,6 +759,53 @@ static void launch_stage2_fused(const QParams &P, size_t Q, const FT *y, int ali
   HIPCHECK(hipGetLastError());
 }
 
+// Stage 2 by selection for queries [xbase, xbase + nq) (stage2_select_kernel), then the literal path for the rows it
+// flagged (device-driven: the flagged list is walked in passes of a bounded workspace, a pass beyond the device-side
+// count exits at once).  out32 / out64: exactly one is non-NULL (precomp's graph rows / query() ids); both are indexed
+// by the global row x.  Returns false -- nothing launched -- when the shape is not taken (the caller runs the classic path).
+static bool stage2_select_with_fallback(const QParams &P, size_t Q, const FT *y, int alias, u32 xbase, size_t nq,
+                                        const u32 *top_i, const FT *top_d, u32 *out32, size_t *out64, FT *out_d,
+                                        DevBuf &flist, u32 *d_fcount, DevBuf &r2i, DevBuf &r2d,
+                                        unsigned long long *exact_total, unsigned long long *rows_ctr, hipStream_t s) {
+  if (!nq) return true;
+  const int K1 = P.k + 1, W = 4, cap = stage1_cap(W, K1);
+  const u32 P2 = P.L2 < 16 ? P.L2 : (u32)1 << ann_lg(P.L2);
+  size_t smem = sizeof(Key) * (size_t)W * cap + 2 * sizeof(Key) * (size_t)W * K1 + sizeof(Key) * (size_t)P.k +
+                sizeof(u32) * (size_t)W * ANN_S1_CHUNK + sizeof(int) * (size_t)W + sizeof(u32) * 4;
+  smem = (smem + 15) & ~(size_t)15;
+  if (d_needs_lds_row(P.d)) smem += sizeof(FT) * (size_t)P.d * (1 + W);
+  const size_t row_bytes = (size_t)P.Lc2 * (sizeof(FT) + sizeof(u32));
+  const size_t chunk = std::max<size_t>(1, ((size_t)1 << 30) / row_bytes);
+  if ((u32)P.k >= P2 || smem > 150 * 1024 || nq > 64 * chunk) return false;
+  u32 *fl = (u32 *)flist.need(sizeof(u32) * nq);
+  zero_u32_kernel<<<1, 1, 0, s>>>(d_fcount);
+#define CALL_T(DD, TT, OUT)                                                                                         \
+  do {                                                                                                              \
+    allow_lds((stage2_select_kernel<DD, TT>), smem);                                                                \
+    hipLaunchKernelGGL((stage2_select_kernel<DD, TT>), dim3((unsigned)nq), dim3(64 * W), smem, s, P, (int)Q, y, alias, \
+                       top_i, top_d, P2, K1, cap, OUT, out_d, fl, d_fcount, exact_total, rows_ctr, xbase);          \
+  } while (0)
+#define CALL(DD)                                   \
+  do {                                             \
+    if (out64) CALL_T(DD, size_t, out64);          \
+    else CALL_T(DD, u32, out32);                   \
+  } while (0)
+  ANN_DISPATCH_D(P.d, CALL);
+#undef CALL
+#undef CALL_T
+  HIPCHECK(hipGetLastError());
+  const size_t R = std::min(nq, chunk);
+  u32 *ri = (u32 *)r2i.need(sizeof(u32) * R * P.Lc2);
+  FT *rd = (FT *)r2d.need(sizeof(FT) * R * P.Lc2);
+  for (size_t p0 = 0; p0 < nq; p0 += R) {
+    const size_t np = std::min(R, nq - p0);
+    launch_rows<MODE_GRAPH>(P, Q, y, alias, NULL, fl + p0, 0, np, P.Lc2, top_i, top_d, ri, rd, rows_ctr, s, d_fcount, (u32)p0);
+    launch_exact_select(P.L2, P.Lc2, P.Lc2, P.k, np, ri, rd, fl + p0, 0, out32, out_d, P.k, 0, s, d_fcount, out64, 1024,
+                        (u32)p0);
+  }
+  return true;
+}
+
 // finalize + exact fallback for the queries finalize1 rejected.  The top-k lands in top_i/top_d
 // (row stride ostride, column offset ooff).  device_driven: no host read-back -- the exact-path kernels are
 // launched over the worst case (every query rejected) and rows beyond the device-side count exit at once;
@@ -915,6 +962,17 @@ static long query_impl(annhip_index *ix, annhip_workspace &ws, hipStream_t s, si
     // one kernel: row assembly, neighbour gathers, network and size_t ids per query (stage2_fused_kernel)
     launch_stage2_fused<size_t>(P, Q, y, alias, 0, Q, top_i, top_d, ids_dev, out_d, rows_ctr, s);
     seg_mark(ix, marks, s);  // "stage2_rows" = the whole fused stage 2; "stage2_network" and "widen" stay 0
+    seg_mark(ix, marks, s);
+    seg_mark(ix, marks, s);
+    if (marks) ix->seg_used.push_back(marks_store);
+    ix->queries += (double)Q;
+    return nflag;
+  }
+  if (ix->lo == 0 && ix->hi == ix->n && env().tail != 0 &&
+      stage2_select_with_fallback(P, Q, y, alias, 0, Q, top_i, top_d, NULL, ids_dev, out_d, ws.flist, ws.d_fcount, ws.r2i,
+                                  ws.r2d, ix->d_rows + 2, rows_ctr, s)) {
+    // long stage-2 rows (k >= 32): selection + proof instead of the P2-entry network; "stage2_rows" = all of it
+    seg_mark(ix, marks, s);
     seg_mark(ix, marks, s);
     seg_mark(ix, marks, s);
     if (marks) ix->seg_used.push_back(marks_store);
@@ -1623,10 +1681,28 @@ extern "C" void annhip_precomp_graph(annhip_precomp *h, size_t row_lo, size_t ro
     if (gd_own) HIPCHECK(hipFree(gd_own));
     return;
   }
+  DevBuf r2i, r2d;
+  if (env().tail != 0 && row_hi > row_lo) {  // long rows: selection + proof, the literal path for the flagged rows only
+    DevBuf fl;
+    u32 *fc = dev_alloc<u32>(4);
+    bool done = true;
+    // rows per call: what the fallback's bounded workspace walks in at most 64 passes (stage2_select_with_fallback)
+    const size_t step = std::min<size_t>((size_t)1 << 22, 64 * std::max<size_t>(1, ((size_t)1 << 30) / ((size_t)P.Lc2 * (sizeof(FT) + sizeof(u32)))));
+    for (size_t q0 = row_lo; q0 < row_hi && done; q0 += step)
+      done = stage2_select_with_fallback(P, n, ix->d_points, 1, (u32)q0, std::min(step, row_hi - q0), h->top_i, h->top_d,
+                                         graph_dev - row_lo * k, NULL, gd - row_lo * k, fl, fc, r2i, r2d, NULL, NULL, s);
+    HIPCHECK(hipStreamSynchronize(s));
+    fl.release();
+    HIPCHECK(hipFree(fc));
+    if (done) {
+      r2i.release(), r2d.release();
+      if (gd_own) HIPCHECK(hipFree(gd_own));
+      return;
+    }
+  }
   const size_t row_bytes = (size_t)P.Lc2 * (sizeof(FT) + sizeof(u32));
   size_t chunk = ((size_t)2 << 30) / row_bytes;
   if (chunk < 1) chunk = 1;
-  DevBuf r2i, r2d;
   for (size_t q0 = row_lo; q0 < row_hi; q0 += chunk) {
     const size_t nq = std::min(chunk, row_hi - q0);
     u32 *ri = (u32 *)r2i.need(sizeof(u32) * nq * P.Lc2);

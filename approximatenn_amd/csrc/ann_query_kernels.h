@@ -490,6 +490,144 @@ __global__ __launch_bounds__(128) void stage2_fused_kernel(QParams P, int Q, con
   if (rows_done && threadIdx.x == 0) atomicAdd(&rows_done[(x & 63u) * 8u], (unsigned long long)got);
 }
 
+// Stage 2 by SELECTION for rows too long for the fused kernel's LDS row (k >= 32: Lc2 > 1024; cfg5: 8 193 entries).
+// What row_dists<GRAPH> + exact_select do with a [Q][Lc2] round trip through HBM and a P2-entry network per query is
+// done by the machinery of stage 1: the workgroup's waves split the first P2 slots of the row (the only ones the
+// reference's network orders, Q1), derive the slot ids (supercharge, compute.cl:252-263), gather the owned valid rows
+// and keep the k+1 smallest distinct keys; slots [0,k) enter with the distances stage 1 gave them.  The output is the
+// first k keys when the finalize1 argument holds for this row: at least k finite distinct keys, no distance shared
+// among the kept ones (a tie between different ids is ordered by the network, Q17), and -- only when the sorted prefix
+// holds no +inf at all, which is the rule here -- k+1 keys were found: the duplicate test at P2-1 reads slot P2's id
+//  and can only ever kill the LARGEST entry of the prefix, which is among the first k outputs only if fewer
+// than k+1 distinct keys exist.  Everything else is appended to `flist` and takes the literal path afterwards.
+template <int D, typename IdOut>
+__global__ __launch_bounds__(256) void stage2_select_kernel(QParams P, int Q, const FT *__restrict__ y, int alias,
+                                                            const u32 *__restrict__ top_id, const FT *__restrict__ top_dist,
+                                                            u32 P2, int K1, int cap, IdOut *__restrict__ out_ids,
+                                                            FT *__restrict__ out_dist, u32 *__restrict__ flist,
+                                                            u32 *__restrict__ fcount,
+                                                            unsigned long long *__restrict__ exact_total,
+                                                            unsigned long long *__restrict__ rows_done, u32 xbase) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = lane_id(), w = threadIdx.x >> 6, W = blockDim.x >> 6;
+  const u32 x = xbase + blockIdx.x;
+  const int k = P.k;
+  // ---- LDS carve-up (mirrored by stage2_select_lds_bytes on the host)
+  unsigned char *sp = smem;
+  Key *kbuf_all = reinterpret_cast<Key *>(sp);   sp += sizeof(Key) * (size_t)W * cap;
+  Key *kout_all = reinterpret_cast<Key *>(sp);   sp += sizeof(Key) * (size_t)W * K1;
+  Key *mbuf = reinterpret_cast<Key *>(sp);       sp += sizeof(Key) * (size_t)W * K1;
+  Key *top = reinterpret_cast<Key *>(sp);        sp += sizeof(Key) * (size_t)k;
+  u32 *list_all = reinterpret_cast<u32 *>(sp);   sp += sizeof(u32) * (size_t)W * ANN_S1_CHUNK;
+  int *mcnt = reinterpret_cast<int *>(sp);       sp += sizeof(int) * (size_t)W;
+  u32 *cnts = reinterpret_cast<u32 *>(sp);       sp += sizeof(u32) * 4;  // [0] finite entries of the prefix [1] rows gathered
+  sp = smem + (((sp - smem) + 15) & ~(size_t)15);
+  FT *yq = reinterpret_cast<FT *>(sp);  // generic d only: [d] + W*[d]
+  u32 *list = list_all + (size_t)w * ANN_S1_CHUNK;
+
+  for (int t = threadIdx.x; t < k; t += blockDim.x) top[t] = key_make(top_dist[(size_t)x * k + t], top_id[(size_t)x * k + t]);
+  if (threadIdx.x < 4) cnts[threadIdx.x] = 0;
+  if constexpr (D == 0)
+    for (int z = threadIdx.x; z < P.d; z += blockDim.x) yq[z] = y[(size_t)x * P.d + z];
+  VT a[RowChunks<D>::C];
+  if constexpr (D > 0) {
+    typedef RowLay<D> L;
+    const VT *yp = reinterpret_cast<const VT *>(y + (size_t)x * D) + (lane % L::LPR);
+#pragma unroll
+    for (int c = 0; c < L::C; c++) a[c] = yp[c * L::LPR];
+  } else if constexpr (D < 0) {
+    const OcLanes<D> ol(P.d, lane);
+    const VT *yp = reinterpret_cast<const VT *>(y + (size_t)x * P.d) + ol.p;
+#pragma unroll
+    for (int c = 0; c < OcCode<D>::C; c++) a[c] = yp[c * ol.oc];
+  }
+  __syncthreads();
+
+  SelState S;
+  S.kbuf = kbuf_all + (size_t)w * cap, S.kout = kout_all + (size_t)w * K1;
+  S.kcnt = 0, S.K1 = K1, S.cap = cap, S.tau = key_max();
+  FT *scratch = yq + (size_t)(1 + w) * P.d;
+  u32 nfin = 0, vown = 0;
+  int cnt = 0;
+  const u32 per = (((P2 + W - 1) / W) + 63u) & ~63u;  // this wave's slice of the sorted prefix [0, P2)
+  const u32 s0 = min(P2, (u32)w * per), s1 = min(P2, s0 + per);
+  for (u32 base = s0; base < s1; base += ANN_WAVE) {
+    const u32 j = base + lane;
+    bool direct = false, ok = false;
+    Key dk = key_max();
+    u32 id = ANN_ID_NONE;
+    if (j < s1) {
+      if (j < (u32)k) {  // the stage-1 result itself, with the distance it already has
+        dk = top[j];
+        direct = key_dist(dk) < ft_inf();
+      } else {
+        const u32 parent = key_id(top[j / k - 1]), z = j % k;
+        id = parent < P.n ? P.graph[(size_t)parent * k + z] : (P.graph[z] | P.n);  // supercharge, Q7
+        ok = id < P.n && !(alias && id == x) && id >= P.lo && id < P.hi;
+      }
+    }
+    nfin += __popcll(__ballot(direct || ok));
+    if (base < (u32)k) {  // wave-uniform: only the first passes of wave 0 hold direct keys
+      if (S.kcnt + ANN_WAVE > S.cap) sel_shrink(S);
+      const bool push = direct && key_less(dk, S.tau);
+      const u64 dm = __ballot(push);
+      if (push) S.kbuf[S.kcnt + mask_rank(dm)] = dk;
+      S.kcnt += __popcll(dm);
+    }
+    const u64 mm = __ballot(ok);
+    if (ok) list[cnt + mask_rank(mm)] = id;
+    cnt += __popcll(mm);
+    if (cnt + ANN_WAVE > ANN_S1_CHUNK) {
+      wave_lds_sync();
+      vown += cnt;
+      gather_select<D>(P, list, cnt, alias, x, a, yq, scratch, S);
+      cnt = 0;
+    }
+  }
+  wave_lds_sync();
+  vown += cnt;
+  gather_select<D>(P, list, cnt, alias, x, a, yq, scratch, S);
+
+  {  // this wave's survivors -> merge buffer
+    const int m = wave_select_smallest(S.kbuf, S.kcnt, K1, S.kout);
+    for (int i = lane; i < m; i += ANN_WAVE) mbuf[(size_t)w * K1 + i] = S.kout[i];
+    if (lane == 0) {
+      mcnt[w] = m;
+      atomicAdd(&cnts[0], nfin);
+      atomicAdd(&cnts[1], vown);
+    }
+  }
+  __syncthreads();
+  if (w == 0) {
+    int total = 0;
+    for (int ww = 0; ww < W; ww++) {  // cap >= W*K1 (host guarantees)
+      const int m = mcnt[ww];
+      for (int i = lane; i < m; i += ANN_WAVE) S.kbuf[total + i] = mbuf[(size_t)ww * K1 + i];
+      total += m;
+    }
+    wave_lds_sync();
+    const int m = wave_select_smallest(S.kbuf, total, K1, S.kout);
+    bool bad = m < k;
+    for (int t = lane; t + 1 < m; t += ANN_WAVE)
+      if (ft_bits(key_dist(S.kout[t])) == ft_bits(key_dist(S.kout[t + 1]))) bad = true;
+    if (m >= k && !(key_dist(S.kout[k - 1]) < ft_inf())) bad = true;
+    if (P.L2 > P2 && cnts[0] >= P2 && m < K1) bad = true;
+    const bool reject = __ballot(bad) != 0;
+    if (reject) {
+      if (lane == 0) {
+        flist[atomicAdd(fcount, 1u)] = x;
+        if (exact_total) atomicAdd(exact_total, 1ull);
+      }
+    } else {
+      for (int t = lane; t < k; t += ANN_WAVE) {
+        out_ids[(size_t)x * k + t] = (IdOut)key_id(S.kout[t]);
+        out_dist[(size_t)x * k + t] = key_dist(S.kout[t]);
+      }
+    }
+    if (rows_done && lane == 0) atomicAdd(&rows_done[(x & 63u) * 8u], (unsigned long long)cnts[1]);
+  }
+}
+
 // One workgroup per query; its waves split the work on the first P1 slots of the candidate row.  Per wave:
 //   A) SEG: for its share of the (try, hamming-neighbour) runs below P1, read the bucket's segment word and copy
 //      the owned ids into an LDS list (prefix sum over the lanes' counts, then a balanced copy);

@@ -44,6 +44,30 @@ def test_cfg5_miniature_large_k(prec):
         save.free()
 
 
+@pytest.mark.parametrize("prec,d,k,dup", [("f32", 64, 40, False), ("f64", 80, 33, False), ("f32", 33, 36, False),
+                                          ("f32", 32, 45, True), ("f64", 128, 32, True)])
+def test_long_stage2_rows_by_selection(prec, d, k, dup):
+    """k >= 32: the stage-2 row (k(k+1) entries) no longer fits the fused kernel's LDS row; precomp's graph stage and
+    query()'s stage 2 run stage2_select_kernel (selection + proof, literal path for the rows it flags).  dup: every point
+    twice => equal distances between different ids everywhere => (nearly) every row is flagged and takes the fallback."""
+    orc, pts, y = _data(prec, 2600, d, 40, 900 + d + k)
+    if dup:
+        pts[1300:] = pts[:1300]
+        y[:10] = pts[5:15]
+    pts, y = np.ascontiguousarray(pts), np.ascontiguousarray(y)
+    orc, (o_ids, o_d, o_save), (ids, dd, save) = _both(prec, pts, y, k, 3)
+    try:
+        assert np.array_equal(ids, o_ids) and bits_equal(dd, o_d)
+        assert_save_equal(save.to_dict(), o_save)
+        want, got = orc.query(o_save, pts, y), A.query(save, pts, y)
+        assert np.array_equal(got[0], want[0]) and bits_equal(got[1], want[1])
+        want, got = orc.query(o_save, pts, 300, alias=True), A.query(save, pts, pts[:300])
+        assert np.array_equal(got[0], want[0]) and bits_equal(got[1], want[1])
+    finally:
+        A._lib.load(prec).annhip_cache_clear()
+        save.free()
+
+
 @pytest.mark.parametrize("d", [16, 512, 1024, 48, 130])
 def test_row_lengths_fast_and_generic(d):
     """smallest / largest register-tiled d, and two generic (non power of two) ones; float."""

@@ -36,6 +36,18 @@ def draw_big_case(rng):
                 seed=rng.randrange(1, 1 << 30), rb=6, rlb=1, ra=1, rla=1)
 
 
+def draw_bigk_case(rng):
+    """k >= 32: stage-2 rows beyond the fused kernel's LDS row (stage2_select_kernel + its literal fallback)."""
+    c = draw_case(rng)
+    c["k"] = rng.choice([32, 33, 40, 50, 64, 100])
+    c["n"] = rng.choice([1200, 2500, 4000])
+    c["T"] = rng.choice([1, 2, 3, 5])
+    c["Q"] = rng.choice([1, 30, 100])
+    c["dup"] = rng.random() < 0.3
+    c["kind"] += "+bigk"
+    return c
+
+
 def draw_case(rng):
     kind = rng.choice(["pow2", "pow2", "static_oc", "static_oc", "chunks", "any"])
     if kind == "pow2":
@@ -119,17 +131,18 @@ def main():
     ap.add_argument("--prec", default="f32,f64")
     ap.add_argument("--sharded", action="store_true")
     ap.add_argument("--big", action="store_true", help="larger shapes (slow: the oracle is the bottleneck)")
+    ap.add_argument("--bigk", action="store_true", help="k >= 32 (long stage-2 rows)")
     a = ap.parse_args()
     rng = random.Random(a.seed)
     bad = 0
     for i in range(a.cases):
-        c = draw_big_case(rng) if a.big else draw_case(rng)
+        c = draw_big_case(rng) if a.big else draw_bigk_case(rng) if a.bigk else draw_case(rng)
         for prec in a.prec.split(","):
             err = run_case(dict(c), prec, a.sharded)
             if err:
                 bad += 1
                 print("MISMATCH (%s) %s %r" % (err, prec, c), flush=True)
-        if (i + 1) % (2 if a.big else 10) == 0:
+        if (i + 1) % (2 if a.big else 5 if a.bigk else 10) == 0:
             print("%d cases done, %d mismatches" % (i + 1, bad), flush=True)
     print("fuzz: %d cases x %s, %d mismatches" % (a.cases, a.prec, bad))
     sys.exit(1 if bad else 0)
