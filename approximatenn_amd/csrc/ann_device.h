@@ -182,6 +182,37 @@ __device__ __forceinline__ void wave_topk_offer(Key &mine, Key &tau, Key key, u6
   }
 }
 
+// Two registers per lane: lanes 0..63 of `lo` hold ranks 0..63, of `hi` ranks 64..127 (K <= 128).  A key that enters
+// `lo` pushes lo's last entry (lane 63) to the front of `hi`.
+__device__ __forceinline__ void wave_topk_shift_in(Key &mine, Key k) {  // k wave-uniform, known not to be listed
+  const Key up = key_lane_prev(mine);
+  if (key_less(k, mine)) mine = key_less(k, up) ? up : k;
+}
+__device__ __forceinline__ void wave_topk_insert2(Key &lo, Key &hi, Key k) {  // k wave-uniform
+  if (__ballot(key_eq(lo, k) || key_eq(hi, k))) return;
+  const Key last = key_readlane(lo, ANN_WAVE - 1);  // key_max() while lo is not full: then k < last
+  if (key_less(k, last)) {
+    wave_topk_shift_in(lo, k);
+    wave_topk_shift_in(hi, last);  // smaller than everything in hi; a no-op for key_max()
+  } else {
+    wave_topk_shift_in(hi, k);
+  }
+}
+__device__ __forceinline__ Key wave_topk_kth2(Key lo, Key hi, int K1) {
+  return K1 <= ANN_WAVE ? key_readlane(lo, K1 - 1) : key_readlane(hi, K1 - 1 - ANN_WAVE);
+}
+__device__ __forceinline__ void wave_topk_offer2(Key &lo, Key &hi, Key &tau, Key key, u64 mm, int K1) {
+  while (mm) {
+    const int src = __builtin_ctzll(mm);
+    mm &= mm - 1;
+    const Key k = key_readlane(key, src);
+    if (key_less(k, tau)) {
+      wave_topk_insert2(lo, hi, k);
+      tau = wave_topk_kth2(lo, hi, K1);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ row layout for power-of-two d
 // A row of D elements is read by LPR lanes as C chunks of 16 bytes per lane; lane position p reads
 // chunks p, p+LPR, ... so that every load instruction covers whole contiguous 128-byte pieces.

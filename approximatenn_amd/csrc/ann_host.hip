@@ -72,6 +72,7 @@ struct EnvCfg {
   size_t lds_row_max = 150 * 1024, exact_bytes = (size_t)1 << 30;
   size_t exact_rows = 0;  // ANN_HIP_EXACT_ROWS: rows of the device-driven exact workspace (0 = auto)
   int cache_mode = 0;  // ANN_HIP_CACHE: 0 sampled fingerprint (default), 1 strict (full content hash), 2 off
+  size_t bk_group = 0;  // ANN_HIP_BK_GROUP: cap on the members per pass of precomp's bucket kernel (0 = what fits the LDS)
 };
 static EnvCfg g_env;
 static size_t env_size(const char *name, size_t dflt) {
@@ -98,6 +99,7 @@ static void load_env() {
   c.lds_row_max = env_size("ANN_HIP_LDS_ROW_MAX", 150 * 1024);
   c.exact_bytes = env_size("ANN_HIP_EXACT_BYTES", (size_t)1 << 30);
   c.exact_rows = env_size("ANN_HIP_EXACT_ROWS", 0);
+  c.bk_group = env_size("ANN_HIP_BK_GROUP", 0);
   const char *cm = getenv("ANN_HIP_CACHE");
   c.cache_mode = !cm ? 0 : !strcmp(cm, "strict") ? 1 : !strcmp(cm, "off") ? 2 : 0;
   g_env = c;
@@ -650,12 +652,18 @@ static void launch_stage1(annhip_index *ix, const QParams &P, size_t Q, const FT
 }
 
 template <int DD>
-static void launch_bucket_d(const QParams &P, size_t nbuckets, int W, int K1, u32 list_cap, size_t smem, FT *cand_d,
+static void launch_bucket_d(const QParams &P, size_t nbuckets, int W, int K1, u32 list_cap, u32 mgroup, size_t smem, FT *cand_d,
                             u32 *cand_i, u32 *nvt, u32 *nvo, hipStream_t s, u32 brem, u32 bmod) {
   if constexpr (DD > 0) {
-    allow_lds(stage1_bucket_kernel<DD>, smem);
-    hipLaunchKernelGGL(stage1_bucket_kernel<DD>, dim3((unsigned)nbuckets), dim3(64 * W), smem, s, P, K1, list_cap, cand_d,
-                       cand_i, nvt, nvo, brem, bmod);
+    if (K1 <= ANN_WAVE) {
+      allow_lds((stage1_bucket_kernel<DD, false>), smem);
+      hipLaunchKernelGGL((stage1_bucket_kernel<DD, false>), dim3((unsigned)nbuckets), dim3(64 * W), smem, s, P, K1, list_cap,
+                         mgroup, cand_d, cand_i, nvt, nvo, brem, bmod);
+    } else {
+      allow_lds((stage1_bucket_kernel<DD, true>), smem);
+      hipLaunchKernelGGL((stage1_bucket_kernel<DD, true>), dim3((unsigned)nbuckets), dim3(64 * W), smem, s, P, K1, list_cap,
+                         mgroup, cand_d, cand_i, nvt, nvo, brem, bmod);
+    }
   }
 }
 
@@ -664,16 +672,20 @@ static bool launch_stage1_bucket(const QParams &P, const TryInfo &one, size_t nb
                                  u32 *nvo, hipStream_t s, u32 brem = 0, u32 bmod = 1) {
   if (!d_is_fast(P.d) || env().point_precomp) return false;
   const int K1 = P.k + 1, W = ANN_BK_WAVES;
-  if (K1 > ANN_WAVE) return false;  // the wave-resident selection holds one key per lane
+  if (K1 > 2 * ANN_WAVE) return false;  // the wave-resident selection holds one or two keys per lane
   const size_t ch = P.d / ANN_VEC, trows = std::max<size_t>(ANN_BK_TILE_CHUNKS / ch, 8);
   const size_t tile = sizeof(VT) * trows * (ch + 1);
   if (P.ds + 1 > ANN_BK_MAX_RUNS) return false;
   const u32 list_cap = std::min<u32>(P.P1, (u32)(P.ds + 1) * one.pm);
-  const size_t smem = tile + sizeof(Key) * (size_t)one.pm * K1 + sizeof(u32) * (size_t)list_cap +
-                      sizeof(u32) * (ANN_BK_MAX_RUNS + 1) + 16;
-  if (smem > 80 * 1024) return false;  // keep two workgroups per CU
+  const size_t fixed = tile + sizeof(u32) * (size_t)list_cap + sizeof(u32) * (ANN_BK_MAX_RUNS + 1) + 16;
+  const size_t budget = 80 * 1024;  // keep two workgroups per CU
+  if (fixed + sizeof(Key) * (size_t)K1 * W > budget) return false;
+  // members whose K1-key lists fit beside the tile; more members than that walk the tiles once per group
+  u32 mgroup = (u32)std::min<size_t>(one.pm, (budget - fixed) / (sizeof(Key) * (size_t)K1));
+  if (env().bk_group) mgroup = (u32)std::min<size_t>(mgroup, std::max<size_t>(env().bk_group, (size_t)W));
+  const size_t smem = fixed + sizeof(Key) * (size_t)mgroup * K1;
   if ((u32)P.k > P.P1) return false;
-#define CALL(DD) launch_bucket_d<DD>(P, nbuckets, W, K1, list_cap, smem, cand_d, cand_i, nvt, nvo, s, brem, bmod)
+#define CALL(DD) launch_bucket_d<DD>(P, nbuckets, W, K1, list_cap, mgroup, smem, cand_d, cand_i, nvt, nvo, s, brem, bmod)
   ANN_DISPATCH_D2(P.d, CALL);
 #undef CALL
   HIPCHECK(hipGetLastError());

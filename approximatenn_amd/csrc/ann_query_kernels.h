@@ -943,8 +943,11 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
 #define ANN_BK_WAVES 4
 #endif
 #define ANN_BK_MAX_RUNS 64
-template <int D>
-__global__ __launch_bounds__(64 * ANN_BK_WAVES) void stage1_bucket_kernel(QParams P, int K1, u32 list_cap,
+// HI: K1 up to 128, two keys per lane (ann_device.h: wave_topk_insert2).  mgroup: members whose lists fit the LDS at a
+// time; a bucket with more members walks the candidate tiles once per group (still members/groups times fewer row
+// reads than the per-point kernel: cfg5, K1 = 101, 16-byte keys: groups of ~33 of up to 118 members).
+template <int D, bool HI>
+__global__ __launch_bounds__(64 * ANN_BK_WAVES) void stage1_bucket_kernel(QParams P, int K1, u32 list_cap, u32 mgroup,
                                                             FT *__restrict__ cand_dist, u32 *__restrict__ cand_id,
                                                             u32 *__restrict__ nv_tot, u32 *__restrict__ nv_own,
                                                             u32 brem, u32 bmod) {
@@ -961,12 +964,11 @@ __global__ __launch_bounds__(64 * ANN_BK_WAVES) void stage1_bucket_kernel(QParam
   constexpr int TROWS = ANN_BK_TILE_CHUNKS / CH >= 8 ? ANN_BK_TILE_CHUNKS / CH : 8;  // rows per tile (>= one wave pass)
   unsigned char *sp = smem;
   VT *tile = reinterpret_cast<VT *>(sp);                 sp += sizeof(VT) * (size_t)TROWS * ROWV;
-  Key *klist = reinterpret_cast<Key *>(sp);              sp += sizeof(Key) * (size_t)pm * K1;  // per member: its K1 best so far
+  Key *klist = reinterpret_cast<Key *>(sp);              sp += sizeof(Key) * (size_t)mgroup * K1;  // per member of the group: its K1 best so far
   u32 *clist = reinterpret_cast<u32 *>(sp);              sp += sizeof(u32) * (size_t)list_cap;  // candidate ids, slot order
   u32 *roff = reinterpret_cast<u32 *>(sp);               sp += sizeof(u32) * (ANN_BK_MAX_RUNS + 1);
   const u32 *mem_ids = tr.tab + (size_t)b * pm;  // members, descending ids
   const u32 ds1 = (u32)P.ds + 1u;
-  for (u32 e = threadIdx.x; e < members * (u32)K1; e += blockDim.x) klist[e] = key_max();
   // valid ids of every run below P1 (the first seg.y entries of the neighbour bucket's row): counts, then offsets
   if (threadIdx.x < ds1) {
     const u32 yy = threadIdx.x, start = yy * pm;
@@ -987,12 +989,15 @@ __global__ __launch_bounds__(64 * ANN_BK_WAVES) void stage1_bucket_kernel(QParam
       clist[roff[yy] + z] = tr.tab[(size_t)nb * pm + z];
     }
   }
-  __syncthreads();
 
   const int p = lane % L::LPR, g = lane / L::LPR;
+  for (u32 g0 = 0; g0 < members; g0 += mgroup) {
+  const u32 gmem = min(mgroup, members - g0);  // members [g0, g0 + gmem) this round
+  __syncthreads();  // clist complete / the previous group's results written
+  for (u32 e = threadIdx.x; e < gmem * (u32)K1; e += blockDim.x) klist[e] = key_max();
   for (u32 r0 = 0; r0 < total; r0 += TROWS) {
     const u32 rows = min((u32)TROWS, total - r0);
-    if (r0) __syncthreads();  // previous tile fully consumed
+    __syncthreads();  // previous tile fully consumed (first tile: the lists are initialised)
     for (u32 e = threadIdx.x; e < rows * CH; e += blockDim.x) {  // whole 128-byte pieces per load instruction
       const u32 r = e / CH, c = e - r * CH;
       tile[(size_t)r * ROWV + c] = load_row_chunk<true>(reinterpret_cast<const VT *>(P.points + (size_t)clist[r0 + r] * D) + c);
@@ -1001,19 +1006,20 @@ __global__ __launch_bounds__(64 * ANN_BK_WAVES) void stage1_bucket_kernel(QParam
     // every wave scores its members, NM at a time, against the tile (a missing member of the last group repeats the
     // group's first one and is masked out)
     constexpr int NM = ANN_BK_MEMBERS;
-    for (u32 m0 = (u32)NM * w; m0 < members; m0 += (u32)NM * W) {
+    for (u32 m0 = (u32)NM * w; m0 < gmem; m0 += (u32)NM * W) {
       u32 mi[NM], xi[NM];
       VT a[NM][L::C];
-      Key mine[NM], tau[NM];
+      Key mine[NM], hi[NM], tau[NM];
 #pragma unroll
       for (int j = 0; j < NM; j++) {
-        mi[j] = m0 + j < members ? m0 + j : m0;
-        xi[j] = mem_ids[mi[j]];
+        mi[j] = m0 + j < gmem ? m0 + j : m0;
+        xi[j] = mem_ids[g0 + mi[j]];
         const VT *yp = reinterpret_cast<const VT *>(P.points + (size_t)xi[j] * D) + p;
 #pragma unroll
         for (int c = 0; c < L::C; c++) a[j][c] = yp[c * L::LPR];
         mine[j] = lane < K1 ? klist[(size_t)mi[j] * K1 + lane] : key_max();
-        tau[j] = key_readlane(mine[j], K1 - 1);
+        hi[j] = (HI && ANN_WAVE + lane < K1) ? klist[(size_t)mi[j] * K1 + ANN_WAVE + lane] : key_max();
+        tau[j] = HI ? wave_topk_kth2(mine[j], hi[j], K1) : key_readlane(mine[j], K1 - 1);
       }
       for (u32 base = 0; base < rows; base += L::RPW) {
         const u32 r = base + g;
@@ -1027,21 +1033,25 @@ __global__ __launch_bounds__(64 * ANN_BK_WAVES) void stage1_bucket_kernel(QParam
 #pragma unroll
         for (int j = 0; j < NM; j++) {
           const Key key = key_make(row_reduce<D, ROW_SQDIFF>(a[j], bv), id);
-          const u64 mm = __ballot(ok && (j == 0 || m0 + j < members) && id != xi[j] && key_less(key, tau[j]));
-          if (mm) wave_topk_offer(mine[j], tau[j], key, mm, K1);
+          const u64 mm = __ballot(ok && (j == 0 || m0 + j < gmem) && id != xi[j] && key_less(key, tau[j]));
+          if (mm) {
+            if constexpr (HI) wave_topk_offer2(mine[j], hi[j], tau[j], key, mm, K1);
+            else wave_topk_offer(mine[j], tau[j], key, mm, K1);
+          }
         }
       }
-      if (lane < K1) {
 #pragma unroll
-        for (int j = 0; j < NM; j++)
-          if (j == 0 || m0 + j < members) klist[(size_t)mi[j] * K1 + lane] = mine[j];
-      }
+      for (int j = 0; j < NM; j++)
+        if (j == 0 || m0 + j < gmem) {
+          if (lane < K1) klist[(size_t)mi[j] * K1 + lane] = mine[j];
+          if (HI && ANN_WAVE + lane < K1) klist[(size_t)mi[j] * K1 + ANN_WAVE + lane] = hi[j];
+        }
     }
   }
   __syncthreads();
   // results: each member's list is already ascending and distinct
-  for (u32 e = threadIdx.x; e < members * (u32)K1; e += blockDim.x) {
-    const u32 m = e / K1, i = e - m * K1, x = mem_ids[m];
+  for (u32 e = threadIdx.x; e < gmem * (u32)K1; e += blockDim.x) {
+    const u32 m = e / K1, i = e - m * K1, x = mem_ids[g0 + m];
     const Key kk = klist[e];
     const bool have = !key_eq(kk, key_max());
     cand_dist[(size_t)x * K1 + i] = have ? key_dist(kk) : ft_inf();
@@ -1051,6 +1061,7 @@ __global__ __launch_bounds__(64 * ANN_BK_WAVES) void stage1_bucket_kernel(QParam
       nv_own[x] = total - 1u;
     }
   }
+  }  // member groups
 }
 
 // -------------------------------------------------------------------------------------- finalize1

@@ -68,6 +68,26 @@ def test_long_stage2_rows_by_selection(prec, d, k, dup):
         save.free()
 
 
+@pytest.mark.parametrize("prec,d,k,group", [("f32", 64, 10, "4"), ("f64", 128, 70, "5"), ("f32", 32, 100, "7"), ("f64", 256, 64, None)])
+def test_bucket_kernel_member_groups_and_two_key_lanes(prec, d, k, group, monkeypatch):
+    """precomp's bucket-centric distance pass: k+1 > 64 keeps two keys per lane (wave_topk_insert2); buckets whose
+    members' lists do not fit the LDS are scored in groups (forced here by ANN_HIP_BK_GROUP).  Few hash bits (large
+    buckets): n = 3000 points in 2^d_short buckets with d_short = 5..6."""
+    if group:
+        monkeypatch.setenv("ANN_HIP_BK_GROUP", group)
+        A._lib.reload_env()
+    orc, pts, y = _data(prec, 3000, d, 16, 400 + d + k)
+    pts[2900:] = pts[:100]          # some exact duplicates: ties inside the lists
+    pts = np.ascontiguousarray(pts)
+    orc, (o_ids, o_d, o_save), (ids, dd, save) = _both(prec, pts, y, k, 2)
+    try:
+        assert np.array_equal(ids, o_ids) and bits_equal(dd, o_d)
+        assert_save_equal(save.to_dict(), o_save)
+    finally:
+        A._lib.load(prec).annhip_cache_clear()
+        save.free()
+
+
 @pytest.mark.parametrize("d", [16, 512, 1024, 48, 130])
 def test_row_lengths_fast_and_generic(d):
     """smallest / largest register-tiled d, and two generic (non power of two) ones; float."""
