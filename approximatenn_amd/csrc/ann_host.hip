@@ -671,7 +671,7 @@ static void launch_bucket_d(const QParams &P, size_t nbuckets, int W, int K1, u3
 static bool launch_stage1_bucket(const QParams &P, const TryInfo &one, size_t nbuckets, FT *cand_d, u32 *cand_i, u32 *nvt,
                                  u32 *nvo, hipStream_t s, u32 brem = 0, u32 bmod = 1) {
   if (!d_is_fast(P.d) || env().point_precomp) return false;
-  const int K1 = P.k + 1, W = ANN_BK_WAVES;
+  const int K1 = P.k + 1, W = K1 > ANN_WAVE ? ANN_BK_WAVES_HI : ANN_BK_WAVES;
   if (K1 > 2 * ANN_WAVE) return false;  // the wave-resident selection holds one or two keys per lane
   const size_t ch = P.d / ANN_VEC, trows = std::max<size_t>(ANN_BK_TILE_CHUNKS / ch, 8);
   const size_t tile = sizeof(VT) * trows * (ch + 1);

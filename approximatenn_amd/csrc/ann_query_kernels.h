@@ -942,12 +942,15 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
 #ifndef ANN_BK_WAVES
 #define ANN_BK_WAVES 4
 #endif
+#ifndef ANN_BK_WAVES_HI
+#define ANN_BK_WAVES_HI 8  // the two-key variant (long lists, few workgroups per CU): cfg5 precomp 40.9 s with 4 waves, 36.5 s with 8
+#endif
 #define ANN_BK_MAX_RUNS 64
 // HI: K1 up to 128, two keys per lane (ann_device.h: wave_topk_insert2).  mgroup: members whose lists fit the LDS at a
 // time; a bucket with more members walks the candidate tiles once per group (still members/groups times fewer row
 // reads than the per-point kernel: cfg5, K1 = 101, 16-byte keys: groups of ~33 of up to 118 members).
 template <int D, bool HI>
-__global__ __launch_bounds__(64 * ANN_BK_WAVES) void stage1_bucket_kernel(QParams P, int K1, u32 list_cap, u32 mgroup,
+__global__ __launch_bounds__(64 * (HI ? ANN_BK_WAVES_HI : ANN_BK_WAVES)) void stage1_bucket_kernel(QParams P, int K1, u32 list_cap, u32 mgroup,
                                                             FT *__restrict__ cand_dist, u32 *__restrict__ cand_id,
                                                             u32 *__restrict__ nv_tot, u32 *__restrict__ nv_own,
                                                             u32 brem, u32 bmod) {
