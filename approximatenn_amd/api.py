@@ -302,6 +302,10 @@ class Index:
     def set_stream(self, stream_ptr):
         self.lib.annhip_index_set_stream(self.h, stream_ptr)
 
+    def set_fixed(self, on=True):
+        """annhip_index_set_fixed: opt-in non-parity query mode (own hash codes, every candidate slot; include/ann_hip.h)."""
+        self.lib.annhip_index_set_fixed(self.h, int(bool(on)))
+
     def workspace(self):
         """annhip_workspace_create: scratch for one in-flight batch (pass to query(ws=..., stream=...))."""
         ws = self.lib.annhip_workspace_create(self.h)

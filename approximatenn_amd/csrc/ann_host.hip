@@ -248,6 +248,7 @@ struct annhip_index {
   double s1_ms = 0;
   double s1_launches = 0, queries = 0;
   int gather_pieces = 1;  // annhip_sh_stage1 in this many launches (annhip_index_set_gather_pieces)
+  int fixed = 0;          // annhip_index_set_fixed: opt-in non-parity query mode (Q1/Q2 undone)
 };
 
 static QParams make_params(const annhip_index *ix) {
@@ -261,6 +262,8 @@ static QParams make_params(const annhip_index *ix) {
   P.d = (int)ix->d, P.k = (int)ix->k, P.T = ix->T, P.ds = (int)ix->ds;
   P.L1 = ix->L1, P.P1 = ix->P1, P.Lc1 = ix->Lc1, P.L2 = ix->L2, P.Lc2 = ix->Lc2;
   P.q0 = 0;
+  P.fixed = ix->fixed ? 1u : 0u;
+  if (ix->fixed) P.P1 = P.Lc1 = P.L1;  // every slot of the candidate row takes part
   return P;
 }
 
@@ -344,6 +347,7 @@ static void check_limits(size_t n, size_t k, size_t d, size_t ds, int T) {
 
 extern "C" void annhip_index_set_stream(annhip_index *ix, void *s) { ix->stream = (hipStream_t)s; }
 extern "C" void annhip_index_set_gather_pieces(annhip_index *ix, int pieces) { ix->gather_pieces = pieces < 1 ? 1 : pieces; }
+extern "C" void annhip_index_set_fixed(annhip_index *ix, int fixed) { ix->fixed = fixed ? 1 : 0; }
 
 extern "C" annhip_index *annhip_index_create(const save_t *save, const ftype *points, int on_device,
                                              size_t row_lo, size_t row_hi) {
@@ -781,7 +785,7 @@ static bool stage2_select_with_fallback(const QParams &P, size_t Q, const FT *y,
                                         unsigned long long *exact_total, unsigned long long *rows_ctr, hipStream_t s) {
   if (!nq) return true;
   const int K1 = P.k + 1, W = 4, cap = stage1_cap(W, K1);
-  const u32 P2 = P.L2 < 16 ? P.L2 : (u32)1 << ann_lg(P.L2);
+  const u32 P2 = (P.L2 < 16 || P.fixed) ? P.L2 : (u32)1 << ann_lg(P.L2);
   size_t smem = sizeof(Key) * (size_t)W * cap + 2 * sizeof(Key) * (size_t)W * K1 + sizeof(Key) * (size_t)P.k +
                 sizeof(u32) * (size_t)W * ANN_S1_CHUNK + sizeof(int) * (size_t)W + sizeof(u32) * 4;
   smem = (smem + 15) & ~(size_t)15;
@@ -806,6 +810,7 @@ static bool stage2_select_with_fallback(const QParams &P, size_t Q, const FT *y,
 #undef CALL
 #undef CALL_T
   HIPCHECK(hipGetLastError());
+  if (P.fixed) return true;  // nothing is ever flagged: the selection IS the result
   const size_t R = std::min(nq, chunk);
   u32 *ri = (u32 *)r2i.need(sizeof(u32) * R * P.Lc2);
   FT *rd = (FT *)r2d.need(sizeof(FT) * R * P.Lc2);
@@ -897,6 +902,7 @@ static void seg_mark(annhip_index *ix, std::vector<hipEvent_t> *marks, hipStream
 // Stage 1 reads code[i*Q + x] for the tries i that own a slot below Lc1, i.e. flat indices below
 // tries_used*Q of the [q*T+t] array, i.e. the codes of queries below ceil(tries_used*Q/T): only those are hashed.
 static size_t codes_needed(const annhip_index *ix, size_t Q) {
+  if (ix->fixed) return Q;
   int tries_used = 0;
   while (tries_used < ix->T && ix->h_tries[tries_used].off < ix->Lc1) tries_used++;
   return std::min(Q, ((size_t)tries_used * Q + ix->T - 1) / ix->T);
@@ -922,6 +928,33 @@ static long query_impl(annhip_index *ix, annhip_workspace &ws, hipStream_t s, si
   FT *top_d = (FT *)ws.top_d.need(sizeof(FT) * Q * k);
   FT *cand_d = NULL;
   u32 *cand_i = NULL, *nvt = NULL;
+  // ---- fixed mode (opt-in, NOT the reference's results): query x hashes into ITS OWN buckets (the
+  // reference reads code[i*Q+x] of a [Q][T] array, Q2), all L1 / L2 slots are candidates (the reference orders the
+  // first 2^floor(log2 L) only, Q1), and the answer is simply the k smallest distinct (distance, id) keys -- stage 1's
+  // selection kernel, finalize1 without its proof, stage 2 by selection.  Single device, whole index.
+  if (ix->fixed) {
+    if (!(ix->lo == 0 && ix->hi == ix->n)) die("fixed mode needs the whole index on this device");
+    cand_d = (FT *)ws.cand_d.need(sizeof(FT) * Q * K1);
+    cand_i = (u32 *)ws.cand_i.need(sizeof(u32) * Q * K1);
+    nvt = (u32 *)ws.nvt.need(sizeof(u32) * Q);
+    u32 *nvo = (u32 *)ws.nvo.need(sizeof(u32) * Q);
+    launch_stage1(ix, P, Q, y, alias, codes, cand_d, cand_i, nvt, nvo, s, ix->h_tries, ix->use_seg);
+    seg_mark(ix, marks, s);
+    hipLaunchKernelGGL(finalize1_kernel, dim3(grid_for(Q, 256, 1u << 30)), dim3(256), 0, s, (int)Q, P.k, K1, P.L1, P.P1,
+                       cand_d, cand_i, nvt, top_i, top_d, k, 0, (u32 *)NULL, (u32 *)NULL, (unsigned long long *)NULL, P.n);
+    HIPCHECK(hipGetLastError());
+    seg_mark(ix, marks, s);
+    FT *out_d = dists_dev ? reinterpret_cast<FT *>(dists_dev) : (FT *)ws.out_d.need(sizeof(FT) * Q * k);
+    if (!stage2_select_with_fallback(P, Q, y, alias, 0, Q, top_i, top_d, NULL, ids_dev, out_d, ws.flist, ws.d_fcount, ws.r2i,
+                                     ws.r2d, NULL, ix->profile ? ix->d_rows + 8 : NULL, s))
+      die("fixed mode: stage-2 shape not supported");
+    seg_mark(ix, marks, s);
+    seg_mark(ix, marks, s);
+    seg_mark(ix, marks, s);
+    if (marks) ix->seg_used.push_back(marks_store);
+    ix->queries += (double)Q;
+    return 0;
+  }
   // ---- fused path: stage 2 runs in the tail of every query's stage-1 workgroup; only rejected queries come back
   {
     const size_t xrow = (size_t)P.Lc1 * (sizeof(FT) + sizeof(u32));

@@ -42,6 +42,8 @@ struct QParams {
   int d, k, T, ds;
   u32 L1, P1, Lc1, L2, Lc2;
   u32 q0;            // stage 1 launched in pieces: the first query of this launch
+  u32 fixed;         // opt-in non-parity mode (annhip_index_set_fixed): a query reads ITS OWN codes (Q2 undone); the host
+                     // also sets P1 = Lc1 = L1 (every slot is a candidate, Q1 undone) and no network decides an order
 };
 
 #define ANN_S1_CHUNK 1024  // slots whose valid ids one wave stages in LDS at a time
@@ -612,16 +614,16 @@ __global__ __launch_bounds__(256) void stage2_select_kernel(QParams P, int Q, co
       if (ft_bits(key_dist(S.kout[t])) == ft_bits(key_dist(S.kout[t + 1]))) bad = true;
     if (m >= k && !(key_dist(S.kout[k - 1]) < ft_inf())) bad = true;
     if (P.L2 > P2 && cnts[0] >= P2 && m < K1) bad = true;
-    const bool reject = __ballot(bad) != 0;
+    const bool reject = !P.fixed && __ballot(bad) != 0;
     if (reject) {
       if (lane == 0) {
         flist[atomicAdd(fcount, 1u)] = x;
         if (exact_total) atomicAdd(exact_total, 1ull);
       }
-    } else {
+    } else {  // (fixed mode: the k smallest distinct keys in (distance, id) order, (+inf, n) where fewer exist)
       for (int t = lane; t < k; t += ANN_WAVE) {
-        out_ids[(size_t)x * k + t] = (IdOut)key_id(S.kout[t]);
-        out_dist[(size_t)x * k + t] = key_dist(S.kout[t]);
+        out_ids[(size_t)x * k + t] = t < m ? (IdOut)key_id(S.kout[t]) : (IdOut)P.n;
+        out_dist[(size_t)x * k + t] = t < m ? key_dist(S.kout[t]) : ft_inf();
       }
     }
     if (rows_done && lane == 0) atomicAdd(&rows_done[(x & 63u) * 8u], (unsigned long long)cnts[1]);
@@ -690,7 +692,7 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
 
   for (int i = threadIdx.x; i < P.T; i += blockDim.x) {
     tries[i] = P.tries[i];
-    qcode[i] = codes[(size_t)i * Q + x];  // Q2: read layout [try][query]
+    qcode[i] = P.fixed ? codes[(size_t)x * P.T + i] : codes[(size_t)i * Q + x];  // Q2: read layout [try][query]
   }
   if (threadIdx.x < 4) cnts[threadIdx.x] = 0;
   if constexpr (D == 0)
@@ -1082,7 +1084,7 @@ __global__ void finalize1_kernel(int Q, int k, int K1, u32 L1, u32 P1, const FT 
                                  const u32 *__restrict__ cand_id, const u32 *__restrict__ nv_tot,
                                  u32 *__restrict__ top_id, FT *__restrict__ top_dist, int ostride,
                                  int ooff, u32 *__restrict__ flist, u32 *__restrict__ fcount,
-                                 unsigned long long *__restrict__ exact_total) {
+                                 unsigned long long *__restrict__ exact_total, u32 fixed_n = 0) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   if (x >= Q) return;
   const FT *cd = cand_dist + (size_t)x * K1;
@@ -1091,6 +1093,13 @@ __global__ void finalize1_kernel(int Q, int k, int K1, u32 L1, u32 P1, const FT 
   bool flag = (u32)k > P1 || K1 != k + 1;
   int m = 0;
   while (m < K1 && ci[m] != ANN_ID_NONE) m++;
+  if (fixed_n) {  // fixed mode (fixed_n = n): the k smallest distinct keys as they are, (+inf, n) where fewer exist
+    for (int t = 0; t < k; t++) {
+      top_id[(size_t)x * ostride + ooff + t] = t < m ? ci[t] : fixed_n;
+      top_dist[(size_t)x * ostride + ooff + t] = t < m ? cd[t] : ft_inf();
+    }
+    return;
+  }
   if (m < k) flag = true;
   if (!flag) {
     if (!(cd[k - 1] < ft_inf())) flag = true;

@@ -329,6 +329,20 @@ def main():
         rk = A.recall_ranks(points, batches[0][:qs].contiguous(), g_ids)
         line["config"]["recall_sample"] = {kk: round(v, 4) for kk, v in A.recall_summary(rk, k).items()}
         line["config"]["recall_sample"]["queries"] = qs
+        # the same sample in the opt-in fixed mode (own hash codes, every candidate slot; include/ann_hip.h): not the
+        # reference's results and never part of `value` -- evidence of what the two accidents cost
+        ix.set_fixed(True)
+        f_ids, _, _ = ix.query(batches[0][:qs].contiguous())
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ix.query(batches[0])
+        torch.cuda.synchronize()
+        f_ms = (time.perf_counter() - t1) * 1e3
+        ix.set_fixed(False)
+        f_ids = torch.where(f_ids >= n, torch.zeros_like(f_ids), f_ids)     # (n, +inf) fillers: any wrong id will do
+        rk = A.recall_ranks(points, batches[0][:qs].contiguous(), f_ids)
+        line["config"]["recall_sample"]["fixed_mode"] = dict({kk: round(v, 4) for kk, v in A.recall_summary(rk, k).items()},
+                                                             ms_per_step=round(f_ms, 4))
     # ---- host-pointer API + CPU baseline share one exported save_t and one host copy of the points
     if not sharded and rank == 0 and not (args.no_cpu_baseline and args.no_host_api):
         if host_pts is None:

@@ -36,6 +36,14 @@ void annhip_index_set_stream(annhip_index *ix, void *hip_stream);
 /* annhip_sh_stage1 launches its gather in `pieces` kernels over consecutive query ranges (default 1).  Same results;
  * the launch boundaries are where workgroups of other streams -- RCCL's in particular -- find free compute units. */
 void annhip_index_set_gather_pieces(annhip_index *ix, int pieces);
+/* Opt-in "fixed" query mode (default 0 = the reference's results, bit for bit).  With 1, annhip_query / annhip_query_on
+ * on this index (whole index on one device) undo two accidents of the reference that cost most of its recall: a query
+ * looks up the buckets of ITS OWN hash codes (the reference reads code[i*Q+x] from an array written as [x*T+i],
+ * alg.c:489-499 vs compute.cl:223-231) and every slot of the candidate row competes (the reference orders only the
+ * first 2^floor(log2 L) slots, alg.c:137-144).  Results: the k smallest distinct (squared distance, id) pairs among the
+ * candidates, stage 2 likewise; (n, +inf) where fewer than k exist.  Not comparable with the reference -- checked
+ * against a brute force over the same candidate sets (tests/test_gpu_fixed_mode.py).  precomp is unaffected. */
+void annhip_index_set_fixed(annhip_index *ix, int fixed);
 /* Point-shard an index that was built from all n rows: from now on this device owns rows [row_lo,row_hi) only
  * and reads them from shard_points_dev (device pointer to those rows, borrowed).  Tables and graph stay. */
 void annhip_index_reshard(annhip_index *ix, const ftype *shard_points_dev, size_t row_lo, size_t row_hi);
