@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32", help="f64 = the reference's stock double build")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-api", action="store_true", help="skip the host-pointer (query_gpu / annhip_stream) extra")
+    ap.add_argument("--fixed-mode-timing", action="store_true",
+                    help="also time one full batch in the opt-in fixed mode (recall_sample.fixed_mode.ms_per_step)")
     ap.add_argument("--no-strong-extra", action="store_true", help="N > 1: skip the fixed-batch (strong scaling) extra")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
@@ -333,16 +335,18 @@ def main():
         # reference's results and never part of `value` -- evidence of what the two accidents cost
         ix.set_fixed(True)
         f_ids, _, _ = ix.query(batches[0][:qs].contiguous())
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        ix.query(batches[0])
-        torch.cuda.synchronize()
-        f_ms = (time.perf_counter() - t1) * 1e3
+        f_ms = None
+        if args.fixed_mode_timing:      # a full batch too (off by default: it would sit among the profiled launches)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            ix.query(batches[0])
+            torch.cuda.synchronize()
+            f_ms = round((time.perf_counter() - t1) * 1e3, 4)
         ix.set_fixed(False)
         f_ids = torch.where(f_ids >= n, torch.zeros_like(f_ids), f_ids)     # (n, +inf) fillers: any wrong id will do
         rk = A.recall_ranks(points, batches[0][:qs].contiguous(), f_ids)
         line["config"]["recall_sample"]["fixed_mode"] = dict({kk: round(v, 4) for kk, v in A.recall_summary(rk, k).items()},
-                                                             ms_per_step=round(f_ms, 4))
+                                                             ms_per_step=f_ms)
     # ---- host-pointer API + CPU baseline share one exported save_t and one host copy of the points
     if not sharded and rank == 0 and not (args.no_cpu_baseline and args.no_host_api):
         if host_pts is None:
