@@ -299,10 +299,14 @@ struct RowChunks<D, true> {
 // shuffles).  OC in {3, 5}: `oc` is static, the groups of OC lanes sit inside the 16-lane DPP rows (16/OC groups per
 // row, the remaining lanes idle) and the whole tail is unrolled at compile time with DPP row shifts -- no LDS crossbar,
 // no run-time control flow (the reference drivers' default d = 80 is OC = 5: C = 4 float chunks / 8 double chunks).
+// D = ANN_D_UNALIGNED: d is NOT a multiple of the 16-byte chunk (d = 33, 50, 77 ...): ceil(d/VEC) lanes share a row, each
+// loads its VEC elements one by one (rows are not 16-byte aligned), zeros beyond d, and the literal tree starts at d.
+#define ANN_D_UNALIGNED (-241)
 template <int D>
 struct OcCode {
+  static constexpr bool UA = D == ANN_D_UNALIGNED;
   static constexpr int C = D < 0 ? ((-D) % 16) : 1;
-  static constexpr int OC = D < 0 ? ((-D) / 16) : 0;
+  static constexpr int OC = (D < 0 && !UA) ? ((-D) / 16) : 0;
 };
 template <int D>
 struct RowChunks<D, false> {
@@ -320,7 +324,8 @@ struct OcLanes {
       const int l = lane & 15;
       oc = OC, rpw = 4 * GPR, g = (lane >> 4) * GPR + l / OC, p = l % OC, valid = l < GPR * OC;
     } else {
-      oc = d / (ANN_VEC * C), rpw = ANN_WAVE / oc, g = lane / oc, p = lane - g * oc, valid = g < rpw;
+      oc = OcCode<D>::UA ? (d + ANN_VEC - 1) / ANN_VEC : d / (ANN_VEC * C);
+      rpw = ANN_WAVE / oc, g = lane / oc, p = lane - g * oc, valid = g < rpw;
     }
   }
 };
@@ -375,7 +380,7 @@ __device__ __forceinline__ void oc_tail(FT (&e)[ANN_VEC], int p) {
 }
 
 template <int C, int MODE, int OC = 0>
-__device__ __forceinline__ FT row_reduce_oc(const VT (&a)[C], const VT (&b)[C], int oc, int p) {
+__device__ __forceinline__ FT row_reduce_oc(const VT (&a)[C], const VT (&b)[C], int oc, int p, int s0 = 0) {  // s0 > 0: tree length (unaligned d)
   FT e[C][ANN_VEC];
 #pragma unroll
   for (int c = 0; c < C; c++) {
@@ -405,7 +410,7 @@ __device__ __forceinline__ FT row_reduce_oc(const VT (&a)[C], const VT (&b)[C], 
     return e[0][0];
   }
   const int lane = lane_id();
-  for (int s = oc * ANN_VEC; s >> 1; s >>= 1) {
+  for (int s = s0 > 0 ? s0 : oc * ANN_VEC; s >> 1; s >>= 1) {
     const int h = s >> 1;
     FT g = zero;
     if (s & 1) {  // g = m[s-1], added into z == 0 only; every lane takes part in the shuffle

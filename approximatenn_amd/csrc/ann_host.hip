@@ -479,6 +479,10 @@ static int layout_code(size_t d, bool allow_oc = true) {
 #endif
     if (oc >= 2 && oc <= 64) return -(int)C;
   }
+#ifndef ANN_NO_UNALIGNED_LAYOUT
+  // d not a multiple of the 16-byte chunk: ceil(d/VEC) lanes per row, element-wise loads, tree of length d
+  if (allow_oc && d % ANN_VEC != 0 && (d + ANN_VEC - 1) / ANN_VEC >= 2 && (d + ANN_VEC - 1) / ANN_VEC <= 64) return ANN_D_UNALIGNED;
+#endif
   return 0;
 }
 #define ANN_DISPATCH_CODE(code, CALL) \
@@ -500,6 +504,7 @@ static int layout_code(size_t d, bool allow_oc = true) {
     case -82: CALL(-82); break;       \
     case -84: CALL(-84); break;       \
     case -88: CALL(-88); break;       \
+    case ANN_D_UNALIGNED: CALL(ANN_D_UNALIGNED); break; \
     default: CALL(0); break;          \
   }
 #ifdef USE_FLOAT

@@ -66,6 +66,26 @@ __device__ __forceinline__ VT load_row_chunk(const VT *p) {
   }
 }
 
+// Chunk `ci` of a row of d elements in the layouts D < 0.  Aligned layouts: one 16-byte load (NT as above); the
+// unaligned one: element by element, zeros beyond d (never read by the tree, which starts at d).
+template <int D, bool NT>
+__device__ __forceinline__ VT oc_load_chunk(const FT *row, int ci, int d) {
+  if constexpr (OcCode<D>::UA) {
+    VT v;
+    FT *o = reinterpret_cast<FT *>(&v);
+#pragma unroll
+    for (int j = 0; j < ANN_VEC; j++) {
+      const int z = ci * ANN_VEC + j;
+      o[j] = z < d ? (NT ? __builtin_nontemporal_load(row + z) : row[z]) : (FT)0;
+    }
+    return v;
+  } else {
+    return load_row_chunk<NT>(reinterpret_cast<const VT *>(row) + ci);
+  }
+}
+template <int D>
+__device__ __forceinline__ int oc_tree_len(int d) { return OcCode<D>::UA ? d : 0; }
+
 // ------------------------------------------------------------------------------------------ codes
 // code[q*T+t] (the reference's WRITE layout; stage 1 reads it back as [i*Q+x]).
 //
@@ -127,11 +147,9 @@ __global__ __launch_bounds__(256) void codes_kernel(QParams P, int Q, const FT *
     const bool live = item < (long)Q * P.T;
     const int q = live ? (int)(item / P.T) : 0, t = live ? (int)(item % P.T) : 0;
     VT a[C];
-    const VT *yp = reinterpret_cast<const VT *>(y + (size_t)q * P.d) + p;
-    const VT *mp = reinterpret_cast<const VT *>(P.means) + p;
 #pragma unroll
     for (int c = 0; c < C; c++) {
-      VT yv = yp[c * oc], mv = mp[c * oc];
+      VT yv = oc_load_chunk<D, false>(y + (size_t)q * P.d, p + c * oc, P.d), mv = oc_load_chunk<D, false>(P.means, p + c * oc, P.d);
       FT *o = reinterpret_cast<FT *>(&a[c]);
       const FT *py = reinterpret_cast<const FT *>(&yv), *pm = reinterpret_cast<const FT *>(&mv);
 #pragma unroll
@@ -141,11 +159,11 @@ __global__ __launch_bounds__(256) void codes_kernel(QParams P, int Q, const FT *
     for (int s0 = 0; s0 < P.ds; s0 += rpw) {
       const int sidx = s0 + g;
       const bool act = ol.valid && sidx < P.ds;
-      const VT *bp = reinterpret_cast<const VT *>(P.bases + ((size_t)t * P.ds + (act ? sidx : 0)) * P.d) + p;
+      const FT *brow = P.bases + ((size_t)t * P.ds + (act ? sidx : 0)) * P.d;
       VT b[C];
 #pragma unroll
-      for (int c = 0; c < C; c++) b[c] = bp[c * oc];
-      FT v = row_reduce_oc<C, ROW_PRODUCT, OC>(a, b, oc, p);
+      for (int c = 0; c < C; c++) b[c] = oc_load_chunk<D, false>(brow, p + c * oc, P.d);
+      FT v = row_reduce_oc<C, ROW_PRODUCT, OC>(a, b, oc, p, oc_tree_len<D>(P.d));
       u32 sign = (u32)(ft_bits(v) >> (sizeof(FT) * 8 - 1));
       if (act && p == 0 && sign) code |= 1u << (P.ds - 1 - sidx);
     }
@@ -326,9 +344,9 @@ __device__ __forceinline__ void gather_select(const QParams &P, const u32 *list,
     u32 idn = 0;
     if (cnt > 0) {
       idn = list[(ol.valid && g < cnt) ? g : 0];
-      const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(idn - P.lo) * P.d) + p;
+      const FT *rp = P.points + (size_t)(idn - P.lo) * P.d;
 #pragma unroll
-      for (int c = 0; c < C; c++) bn[c] = load_row_chunk<true>(rp + c * oc);
+      for (int c = 0; c < C; c++) bn[c] = oc_load_chunk<D, true>(rp, p + c * oc, P.d);
     }
     for (int base = 0; base < cnt; base += rpw) {
       VT b[C];
@@ -339,11 +357,11 @@ __device__ __forceinline__ void gather_select(const QParams &P, const u32 *list,
       const int nb = base + rpw;
       if (nb < cnt) {
         idn = list[(ol.valid && nb + g < cnt) ? nb + g : nb];
-        const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(idn - P.lo) * P.d) + p;
+        const FT *rp = P.points + (size_t)(idn - P.lo) * P.d;
 #pragma unroll
-        for (int c = 0; c < C; c++) bn[c] = load_row_chunk<true>(rp + c * oc);
+        for (int c = 0; c < C; c++) bn[c] = oc_load_chunk<D, true>(rp, p + c * oc, P.d);
       }
-      const FT dist = row_reduce_oc<C, ROW_SQDIFF, OC>(a, b, oc, p);
+      const FT dist = row_reduce_oc<C, ROW_SQDIFF, OC>(a, b, oc, p, oc_tree_len<D>(P.d));
       const Key key = key_make(dist, id);
       const bool pass = act && p == 0 && key_less(key, S.tau);
       const u64 mm = __ballot(pass);
@@ -423,11 +441,11 @@ __device__ __forceinline__ u32 stage2_in_workgroup(const QParams &P, u32 x, int 
       const int r = base + g;
       const bool act = ol.valid && r < cnt2;
       const u32 id = t_gid[act ? r : base];
-      const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(id - P.lo) * P.d) + p;
+      const FT *rp = P.points + (size_t)(id - P.lo) * P.d;
       VT b[C];
 #pragma unroll
-      for (int c = 0; c < C; c++) b[c] = load_row_chunk<true>(rp + c * oc);
-      const FT dist = row_reduce_oc<C, ROW_SQDIFF, OC>(a, b, oc, p);
+      for (int c = 0; c < C; c++) b[c] = oc_load_chunk<D, true>(rp, p + c * oc, P.d);
+      const FT dist = row_reduce_oc<C, ROW_SQDIFF, OC>(a, b, oc, p, oc_tree_len<D>(P.d));
       if (act && p == 0) t_dist[t_slot[r]] = dist;
     }
   } else {
@@ -482,9 +500,8 @@ __global__ __launch_bounds__(128) void stage2_fused_kernel(QParams P, int Q, con
     for (int c = 0; c < L::C; c++) a[c] = yp[c * L::LPR];
   } else if constexpr (D < 0) {
     const OcLanes<D> ol(P.d, lane);
-    const VT *yp = reinterpret_cast<const VT *>(y + (size_t)x * P.d) + ol.p;
 #pragma unroll
-    for (int c = 0; c < OcCode<D>::C; c++) a[c] = yp[c * ol.oc];
+    for (int c = 0; c < OcCode<D>::C; c++) a[c] = oc_load_chunk<D, false>(y + (size_t)x * P.d, ol.p + c * ol.oc, P.d);
   }
   __syncthreads();
   const u32 got = stage2_in_workgroup<D, IdOut>(P, x, alias, a, yq, yq + (size_t)(1 + w) * P.d, top, k, len2, t_ids, t_slot,
@@ -539,9 +556,8 @@ __global__ __launch_bounds__(256) void stage2_select_kernel(QParams P, int Q, co
     for (int c = 0; c < L::C; c++) a[c] = yp[c * L::LPR];
   } else if constexpr (D < 0) {
     const OcLanes<D> ol(P.d, lane);
-    const VT *yp = reinterpret_cast<const VT *>(y + (size_t)x * P.d) + ol.p;
 #pragma unroll
-    for (int c = 0; c < OcCode<D>::C; c++) a[c] = yp[c * ol.oc];
+    for (int c = 0; c < OcCode<D>::C; c++) a[c] = oc_load_chunk<D, false>(y + (size_t)x * P.d, ol.p + c * ol.oc, P.d);
   }
   __syncthreads();
 
@@ -714,9 +730,8 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
     for (int c = 0; c < L::C; c++) a[c] = yp[c * L::LPR];
   } else if constexpr (D < 0) {
     const OcLanes<D> ol(P.d, lane);
-    const VT *yp = reinterpret_cast<const VT *>(y + (size_t)x * P.d) + ol.p;
 #pragma unroll
-    for (int c = 0; c < OcCode<D>::C; c++) a[c] = yp[c * ol.oc];
+    for (int c = 0; c < OcCode<D>::C; c++) a[c] = oc_load_chunk<D, false>(y + (size_t)x * P.d, ol.p + c * ol.oc, P.d);
   }
 
   int cnt = 0;
@@ -1185,9 +1200,8 @@ __global__ __launch_bounds__(256) void row_dists_kernel(QParams P, int Q, const 
     for (int c = 0; c < L::C; c++) a[c] = yp[c * L::LPR];
   } else if constexpr (D < 0) {
     const OcLanes<D> ol(P.d, lane);
-    const VT *yp = reinterpret_cast<const VT *>(y + (size_t)x * P.d) + ol.p;
 #pragma unroll
-    for (int c = 0; c < OcCode<D>::C; c++) a[c] = yp[c * ol.oc];
+    for (int c = 0; c < OcCode<D>::C; c++) a[c] = oc_load_chunk<D, false>(y + (size_t)x * P.d, ol.p + c * ol.oc, P.d);
   }
   u32 gathered = 0;
   // gridDim.y workgroups share one row: each takes every gridDim.y-th chunk of its slots
@@ -1252,11 +1266,11 @@ __global__ __launch_bounds__(256) void row_dists_kernel(QParams P, int Q, const 
         const int r = base + g;
         const bool act = ol.valid && r < cnt;
         const u32 id = lid[act ? r : base];
-        const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(id - P.lo) * P.d) + p;
+        const FT *rp = P.points + (size_t)(id - P.lo) * P.d;
         VT b[C];
 #pragma unroll
-        for (int c = 0; c < C; c++) b[c] = load_row_chunk<true>(rp + c * oc);
-        const FT dist = row_reduce_oc<C, ROW_SQDIFF, OC>(a, b, oc, p);
+        for (int c = 0; c < C; c++) b[c] = oc_load_chunk<D, true>(rp, p + c * oc, P.d);
+        const FT dist = row_reduce_oc<C, ROW_SQDIFF, OC>(a, b, oc, p, oc_tree_len<D>(P.d));
         if (act && p == 0) dist_row[lslot[r]] = dist;
       }
     } else {
