@@ -352,11 +352,9 @@ class ShardedQuery:
             self._to_owner(L.s2_in, L.s2)
             e.sh_final(G, Q, q_lo, qs, L.top_i, L.top_d, L.s2_in, L.out_i_slice, L.out_d_slice)
             self._gather_cat(L.pack_all, L.pack.view(1, -1))
-            L.out_d.view(G, qs * e.k).copy_(L.pack_all[:, : L.nb_d].view(e.ft))
-            L.out_i.view(G, qs * e.k).copy_(L.pack_all[:, L.nb_d: L.nb_d + L.nb_i].view(torch.int32))
-            L.head_dev[0:1].copy_(L.flagged[0:1])
-            L.head_dev[1:2].copy_(L.flist[1:2])
-            L.head_host.copy_(L.head_dev, non_blocking=True)
+            # (the packed rows are unpacked in collect(): straight into the 64-bit ids / the returned distances)
+            L.head_host[0:1].copy_(L.flagged[0:1], non_blocking=True)
+            L.head_host[1:2].copy_(L.flist[1:2], non_blocking=True)
             if L.stream is not None:
                 if L.event is None:
                     L.event = e.new_event()
@@ -374,12 +372,22 @@ class ShardedQuery:
         nf = int(L.head_host[0])              # flagged queries the device-driven exact path had no room for; the same
         self.last_exact = int(L.head_host[1])  # on every rank.  [1] = all flagged queries of the batch
         with e.use(L.stream):
-            if nf:
+            Q, G, qs = L.Q, self.world, L.qs
+            packed_d = L.pack_all[:, : L.nb_d].view(e.ft)                               # [G, qs*k]
+            packed_i = L.pack_all[:, L.nb_d: L.nb_d + L.nb_i].view(torch.int32)
+            ids = torch.empty((G * qs, e.k), dtype=torch.int64, device=L.pack_all.device)   # fresh: the lane is re-used
+            dd = torch.empty((G * qs, e.k), dtype=e.ft, device=L.pack_all.device)
+            if nf:                                                   # rare: the repair patches rows of out_i / out_d
+                L.out_d.view(G, qs * e.k).copy_(packed_d)
+                L.out_i.view(G, qs * e.k).copy_(packed_i)
                 self._repair(L, nf)
-            Q = L.Q
-            L.ids64.copy_(L.out_i)                                   # u32 bit patterns -> the ABI's 64-bit ids
-            L.ids64.bitwise_and_(0xFFFFFFFF)
-            ids, dd = L.ids64[:Q].clone(), L.out_d[:Q].clone()
+                ids.copy_(L.out_i)
+                dd.copy_(L.out_d)
+            else:
+                ids.view(G, qs * e.k).copy_(packed_i)
+                dd.view(G, qs * e.k).copy_(packed_d)
+            ids.bitwise_and_(0xFFFFFFFF)                             # u32 bit patterns -> the ABI's 64-bit ids
+            ids, dd = ids[:Q], dd[:Q]
             if L.stream is not None:
                 torch.cuda.current_stream(L.y.device).wait_stream(L.stream)
         L.busy, L.y = False, None
