@@ -302,9 +302,21 @@ struct RowChunks<D, true> {
 // D = ANN_D_UNALIGNED: d is NOT a multiple of the 16-byte chunk (d = 33, 50, 77 ...): ceil(d/VEC) lanes share a row, each
 // loads its VEC elements one by one (rows are not 16-byte aligned), zeros beyond d, and the literal tree starts at d.
 #define ANN_D_UNALIGNED (-241)
+// D = ANN_D_FOLD2 / ANN_D_FOLD3: as ANN_D_UNALIGNED everywhere (element-wise loads work for aligned rows too), except in
+// the selection gathers, which fold the first 2 / 3 tree levels into a lane (ann_query_kernels.h: gather_fold).  Own
+// codes, not a run-time branch: the folded code's registers would cost the other row lengths their occupancy.
+#define ANN_D_FOLD2 (-243)
+#define ANN_D_FOLD3 (-244)
+// levels of the literal tree folded into a lane for a row of d elements: halve until <= 16 values remain (0: none)
+__host__ __device__ inline int ann_fold_levels(int d) {
+  int s = d, L = 0;
+  while (L < 5 && s > 16) s >>= 1, L++;
+  return s > 64 ? 0 : L;
+}
 template <int D>
 struct OcCode {
-  static constexpr bool UA = D == ANN_D_UNALIGNED;
+  static constexpr int FOLD = D == ANN_D_FOLD2 ? 2 : D == ANN_D_FOLD3 ? 3 : 0;
+  static constexpr bool UA = D == ANN_D_UNALIGNED || FOLD > 0;
   static constexpr int C = D < 0 ? ((-D) % 16) : 1;
   static constexpr int OC = (D < 0 && !UA) ? ((-D) / 16) : 0;
 };

@@ -470,6 +470,7 @@ extern "C" void annhip_index_export(const annhip_index *ix, save_t *save) {
 // drivers' default d = 80) and OC = 0 where oc comes at run time; D = 0 = any d (literal tree through LDS).
 static int layout_code(size_t d, bool allow_oc = true) {
   if (d >= 16 && (d & (d - 1)) == 0 && d <= (sizeof(FT) == 4 ? 1024u : 512u)) return (int)d;
+  bool static_oc = false;
   if (allow_oc && d % ANN_VEC == 0) {
     size_t nc = d / ANN_VEC, C = 1;
     while (C < 8 && nc % (2 * C) == 0) C *= 2;
@@ -477,6 +478,20 @@ static int layout_code(size_t d, bool allow_oc = true) {
 #ifndef ANN_NO_STATIC_OC
     if ((oc == 3 || oc == 5) && C >= 2) return -(int)(16 * oc + C);  // static layout, DPP-only tail (d = 80: oc = 5)
 #endif
+    static_oc = C > 2;  // many 16-byte chunks per lane: the aligned layout below beats the fold (d = 384: 4.0 vs 2.4 TB/s)
+  }
+#ifndef ANN_NO_FOLD
+  // 2 or 3 tree levels folded into a lane (4 or 8 leaves; roughly 33 <= d <= 128): d = 100 float 0.76 -> 1.7 TB/s
+  if (allow_oc && !static_oc && (d + ANN_VEC - 1) / ANN_VEC <= 64) {
+    const int L = ann_fold_levels((int)d);
+    if (L == 2) return ANN_D_FOLD2;
+    if (L == 3) return ANN_D_FOLD3;
+  }
+#endif
+  if (allow_oc && d % ANN_VEC == 0) {
+    size_t nc = d / ANN_VEC, C = 1;
+    while (C < 8 && nc % (2 * C) == 0) C *= 2;
+    const size_t oc = nc / C;
     if (oc >= 2 && oc <= 64) return -(int)C;
   }
 #ifndef ANN_NO_UNALIGNED_LAYOUT
@@ -505,6 +520,8 @@ static int layout_code(size_t d, bool allow_oc = true) {
     case -84: CALL(-84); break;       \
     case -88: CALL(-88); break;       \
     case ANN_D_UNALIGNED: CALL(ANN_D_UNALIGNED); break; \
+    case ANN_D_FOLD2: CALL(ANN_D_FOLD2); break; \
+    case ANN_D_FOLD3: CALL(ANN_D_FOLD3); break; \
     default: CALL(0); break;          \
   }
 #ifdef USE_FLOAT

@@ -283,12 +283,135 @@ __device__ __forceinline__ void sel_shrink(SelState &S) {
   wave_lds_sync();
 }
 
+// ---- folded layout for row lengths that are not a power of two (d = 100, 200, 384, 768, 33, 77 ...).
+// The literal tree (compute.cl:160-167) halves s = d, d>>1, ... and at each level adds m[z + h] (and, into z = 0, the
+// left-over m[s-1] of an odd s) to m[z].  Its first L levels are folded INTO a lane: lane z < s_L of a row's lane group
+// holds the 2^L leaves z + sum of a subset of {h_1..h_L} and reduces them with the same additions in the same order
+// (a bit-butterfly: level l combines the leaves that differ in bit l-1); the left-over of an odd level is a regular
+// subtree of the lower levels and is computed by lane 0 alone.  What remains are s_L <= 16 values, one per lane, whose
+// tree takes one or two shuffles per level.  Against the lanes-per-row layout with shuffles from the first level on
+// (row_reduce_oc, OC = 0): d = 100 float needs 5 shuffles per 5 rows instead of ~30 per 2 rows.
+struct FoldPlan {
+  int L, sL;
+  int h[5], odd[5], sprev[5];
+  __device__ __forceinline__ explicit FoldPlan(int d) {
+    int s = d;
+    L = 0;
+    while (L < 5 && s > 16) {
+      sprev[L] = s, h[L] = s >> 1, odd[L] = s & 1;
+      s >>= 1;
+      L++;
+    }
+    sL = s;
+    if (sL > 64) L = 0;  // not representable: the caller keeps its own layout
+  }
+};
+
+template <int LV>
+__device__ __forceinline__ void gather_fold(const QParams &P, const FoldPlan &fp, const u32 *list, int cnt, int alias, u32 x,
+                                            const FT *yrow, SelState &S) {
+  constexpr int NL = 1 << LV;
+  const int lane = lane_id(), d = P.d, sL = fp.sL, rpw = ANN_WAVE / sL;
+  const int g = lane / sL, z = lane - g * sL;
+  const bool valid = g < rpw;
+  const FT zero = 0;
+  int off[NL];
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    off[i] = 0;
+#pragma unroll
+    for (int l = 0; l < LV; l++)
+      if ((i >> l) & 1) off[i] += fp.h[l];
+  }
+  FT a[NL], ax[NL];  // the query's leaves; ax[(1 << l) + i]: leaf i of the left-over subtree of level l (lane z == 0 only)
+#pragma unroll
+  for (int i = 0; i < NL; i++) a[i] = yrow[z + off[i]], ax[i] = zero;
+  if (z == 0) {
+#pragma unroll
+    for (int l = 0; l < LV; l++)
+      if (fp.odd[l]) {
+#pragma unroll
+        for (int i = 0; i < (1 << l); i++) ax[(1 << l) + i] = yrow[fp.sprev[l] - 1 + off[i]];
+      }
+  }
+  FT bn[NL];
+  u32 idn = 0;
+  if (cnt > 0) {
+    idn = list[(valid && g < cnt) ? g : 0];
+    const FT *rp = P.points + (size_t)(idn - P.lo) * d + z;
+#pragma unroll
+    for (int i = 0; i < NL; i++) bn[i] = __builtin_nontemporal_load(rp + off[i]);
+  }
+  for (int base = 0; base < cnt; base += rpw) {
+    FT e[NL];
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const FT t = a[i] - bn[i];
+      e[i] = t * t;
+    }
+    const u32 id = idn;
+    const bool act = valid && base + g < cnt && !(alias && id == x);
+    FT gx[LV];
+#pragma unroll
+    for (int l = 0; l < LV; l++) gx[l] = zero;
+    // left-overs of the odd levels: regular subtrees of the levels below, lane 0 of each group only.  (Loading them
+    // with the row and computing them in every lane was tried: the extra VALU work costs more than the divergence.)
+    if (z == 0) {
+      const FT *rp0 = P.points + (size_t)(id - P.lo) * d;
+#pragma unroll
+      for (int l = 0; l < LV; l++)
+        if (fp.odd[l]) {
+          FT t[NL];  // 2^l of them are used (every bound below is a constant once the loops are unrolled)
+#pragma unroll
+          for (int i = 0; i < NL; i++)
+            if (i < (1 << l)) {
+              const FT df = ax[(1 << l) + i] - __builtin_nontemporal_load(rp0 + fp.sprev[l] - 1 + off[i]);
+              t[i] = df * df;
+            }
+#pragma unroll
+          for (int j = 0; j < LV; j++)
+#pragma unroll
+            for (int i = 0; i < NL; i += 2 << j)
+              if (j < l && i < (1 << l)) t[i] = t[i] + (t[i + (1 << j)] + zero);
+          gx[l] = t[0];
+        }
+    }
+    const int nb = base + rpw;
+    if (nb < cnt) {  // next pass in flight while this one is reduced
+      idn = list[(valid && nb + g < cnt) ? nb + g : nb];
+      const FT *rp = P.points + (size_t)(idn - P.lo) * d + z;
+#pragma unroll
+      for (int i = 0; i < NL; i++) bn[i] = __builtin_nontemporal_load(rp + off[i]);
+    }
+#pragma unroll
+    for (int l = 0; l < LV; l++)
+#pragma unroll
+      for (int i = 0; i < NL; i += 2 << l) e[i] = e[i] + (e[i + (1 << l)] + (i == 0 ? gx[l] : zero));
+    FT v = e[0];
+    for (int s = sL; s >> 1; s >>= 1) {  // the remaining tree: value z in lane z of the group
+      const int h = s >> 1;
+      const FT o = __shfl(v, lane + h);
+      FT gg = zero;
+      if (s & 1) gg = __shfl(v, lane - z + s - 1);
+      if (z < h) v = v + (o + (z == 0 ? gg : zero));
+    }
+    const Key key = key_make(v, id);
+    const bool pass = act && z == 0 && key_less(key, S.tau);
+    const u64 mm = __ballot(pass);
+    if (mm) {
+      if (pass) S.kbuf[S.kcnt + mask_rank(mm)] = key;
+      S.kcnt += __popcll(mm);
+      if (S.kcnt + rpw > S.cap) sel_shrink(S);
+    }
+  }
+}
+
 // B) gather the rows listed in list[0..cnt) (LDS), squared L2 to the query in the reference's tree order, keep
 // the keys that can still matter.  D > 0: LPR lanes per row, the next pass is prefetched while this one is reduced.
 template <int D>
 __device__ __forceinline__ void gather_select(const QParams &P, const u32 *list, int cnt, int alias, u32 x,
                                               const VT (&a)[RowChunks<D>::C],
-                                              const FT *yq, FT *scratch, SelState &S) {
+                                              const FT *yq, FT *scratch, SelState &S, const FT *yrow = NULL) {
   const int lane = lane_id();
   if constexpr (D > 0) {
     // PF row buffers per lane form a ring: while pass i is reduced, the loads of passes i+1 .. i+PF-1 are in flight
@@ -338,6 +461,12 @@ __device__ __forceinline__ void gather_select(const QParams &P, const u32 *list,
     }
   } else if constexpr (D < 0) {
     constexpr int C = OcCode<D>::C, OC = OcCode<D>::OC;
+    if constexpr (OcCode<D>::FOLD > 0) {  // the first tree levels inside a lane (host: layout_code chose this d for it)
+      const FoldPlan fp(P.d);
+      gather_fold<OcCode<D>::FOLD>(P, fp, list, cnt, alias, x, yrow, S);
+      wave_lds_sync();
+      return;
+    }
     const OcLanes<D> ol(P.d, lane);
     const int oc = ol.oc, rpw = ol.rpw, g = ol.g, p = ol.p;  // lanes with !ol.valid have no row
     VT bn[C];
@@ -598,13 +727,13 @@ __global__ __launch_bounds__(256) void stage2_select_kernel(QParams P, int Q, co
     if (cnt + ANN_WAVE > ANN_S1_CHUNK) {
       wave_lds_sync();
       vown += cnt;
-      gather_select<D>(P, list, cnt, alias, x, a, yq, scratch, S);
+      gather_select<D>(P, list, cnt, alias, x, a, yq, scratch, S, y + (size_t)x * P.d);
       cnt = 0;
     }
   }
   wave_lds_sync();
   vown += cnt;
-  gather_select<D>(P, list, cnt, alias, x, a, yq, scratch, S);
+  gather_select<D>(P, list, cnt, alias, x, a, yq, scratch, S, y + (size_t)x * P.d);
 
   {  // this wave's survivors -> merge buffer
     const int m = wave_select_smallest(S.kbuf, S.kcnt, K1, S.kout);
@@ -784,7 +913,7 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
         if (lo < ANN_WAVE) {  // the next run does not fit any more: drain the list (a run is at most pm <= 255 ids)
           wave_lds_sync();
           vown += cnt;
-          gather_select<D>(P, list, cnt, alias, x, a, yq, scratch, S);
+          gather_select<D>(P, list, cnt, alias, x, a, yq, scratch, S, y + (size_t)x * P.d);
           cnt = 0;
         }
       }
@@ -832,7 +961,7 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
         if (cnt == ANN_S1_CHUNK) {
           wave_lds_sync();
           vown += cnt;
-          gather_select<D>(P, list, cnt, alias, x, a, yq, scratch, S);
+          gather_select<D>(P, list, cnt, alias, x, a, yq, scratch, S, y + (size_t)x * P.d);
           cnt = 0;
         }
       }
@@ -859,14 +988,14 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
       if (cnt + ANN_WAVE > ANN_S1_CHUNK) {
         wave_lds_sync();
         vown += cnt;
-        gather_select<D>(P, list, cnt, alias, x, a, yq, scratch, S);
+        gather_select<D>(P, list, cnt, alias, x, a, yq, scratch, S, y + (size_t)x * P.d);
         cnt = 0;
       }
     }
   }
   wave_lds_sync();
   vown += cnt;
-  gather_select<D>(P, list, cnt, alias, x, a, yq, scratch, S);
+  gather_select<D>(P, list, cnt, alias, x, a, yq, scratch, S, y + (size_t)x * P.d);
 
   // ---- this wave's survivors -> merge buffer
   {
