@@ -307,6 +307,7 @@ struct RowChunks<D, true> {
 // codes, not a run-time branch: the folded code's registers would cost the other row lengths their occupancy.
 #define ANN_D_FOLD2 (-243)
 #define ANN_D_FOLD3 (-244)
+#define ANN_D_FOLD4 (-245)
 // levels of the literal tree folded into a lane for a row of d elements: halve until <= 16 values remain (0: none)
 __host__ __device__ inline int ann_fold_levels(int d) {
   int s = d, L = 0;
@@ -315,7 +316,7 @@ __host__ __device__ inline int ann_fold_levels(int d) {
 }
 template <int D>
 struct OcCode {
-  static constexpr int FOLD = D == ANN_D_FOLD2 ? 2 : D == ANN_D_FOLD3 ? 3 : 0;
+  static constexpr int FOLD = D == ANN_D_FOLD2 ? 2 : D == ANN_D_FOLD3 ? 3 : D == ANN_D_FOLD4 ? 4 : 0;
   static constexpr bool UA = D == ANN_D_UNALIGNED || FOLD > 0;
   static constexpr int C = D < 0 ? ((-D) % 16) : 1;
   static constexpr int OC = (D < 0 && !UA) ? ((-D) / 16) : 0;

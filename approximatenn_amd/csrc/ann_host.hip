@@ -486,6 +486,9 @@ static int layout_code(size_t d, bool allow_oc = true) {
     const int L = ann_fold_levels((int)d);
     if (L == 2) return ANN_D_FOLD2;
     if (L == 3) return ANN_D_FOLD3;
+    // four levels (16 leaves) only where the rows are unaligned anyway: for aligned d the element loads of the OTHER
+    // kernels cost what the gathers gain (d=136: stage 1 3.1 -> 2.8 ms but 2.7 -> 2.2 M q/s; d=250: 0.51 -> 1.0 M q/s)
+    if (L == 4 && d % ANN_VEC != 0) return ANN_D_FOLD4;
   }
 #endif
   if (allow_oc && d % ANN_VEC == 0) {
@@ -522,8 +525,10 @@ static int layout_code(size_t d, bool allow_oc = true) {
     case ANN_D_UNALIGNED: CALL(ANN_D_UNALIGNED); break; \
     case ANN_D_FOLD2: CALL(ANN_D_FOLD2); break; \
     case ANN_D_FOLD3: CALL(ANN_D_FOLD3); break; \
+    ANN_CASE_FOLD4(CALL) \
     default: CALL(0); break;          \
   }
+#define ANN_CASE_FOLD4(CALL) case ANN_D_FOLD4: CALL(ANN_D_FOLD4); break;
 #ifdef USE_FLOAT
 #define ANN_CASE_1024(CALL) case 1024: CALL(1024); break;
 #else

@@ -88,6 +88,25 @@ def test_bucket_kernel_member_groups_and_two_key_lanes(prec, d, k, group, monkey
         save.free()
 
 
+@pytest.mark.parametrize("prec,d", [("f32", 36), ("f32", 50), ("f32", 77), ("f32", 100), ("f64", 100), ("f32", 150),
+                                    ("f32", 250), ("f64", 72), ("f64", 77), ("f32", 200), ("f32", 300)])
+def test_row_lengths_folded_and_neighbours(prec, d):
+    """Row lengths of the folded layouts (2, 3 or -- unaligned only -- 4 tree levels inside a lane), with odd levels at
+    different depths (77: levels 1 and 3; 100: level 3; 150: level 2; 250: levels 2 and 4), and their neighbours that keep
+    the lanes-per-row layout (200) or the tree through LDS (300)."""
+    orc, pts, y = _data(prec, 900, d, 40, 300 + d)
+    orc, (o_ids, o_d, o_save), (ids, dd, save) = _both(prec, pts, y, 6, 3)
+    try:
+        assert np.array_equal(ids, o_ids) and bits_equal(dd, o_d)
+        want, got = orc.query(o_save, pts, y), A.query(save, pts, y)
+        assert np.array_equal(got[0], want[0]) and bits_equal(got[1], want[1])
+        want, got = orc.query(o_save, pts, 200, alias=True), A.query(save, pts, pts[:200])
+        assert np.array_equal(got[0], want[0]) and bits_equal(got[1], want[1])
+    finally:
+        A._lib.load(prec).annhip_cache_clear()
+        save.free()
+
+
 @pytest.mark.parametrize("d", [16, 512, 1024, 48, 130])
 def test_row_lengths_fast_and_generic(d):
     """smallest / largest register-tiled d, and two generic (non power of two) ones; float."""

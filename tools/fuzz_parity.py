@@ -57,7 +57,7 @@ def draw_case(rng):
     elif kind == "chunks":
         d = rng.choice([20, 28, 36, 44, 52, 60, 72, 100, 112, 144])
     else:
-        d = rng.choice([17, 19, 23, 33, 50, 65, 77, 130])
+        d = rng.choice([17, 19, 23, 33, 50, 65, 77, 130, 150, 250])
     k = rng.choice([1, 2, 3, 5, 8, 10, 10, 10, 16, 17, 25, 40])
     n = rng.choice([300, 700, 1000, 2500, 6000])
     if n <= 4 * k:
