@@ -308,6 +308,11 @@ struct RowChunks<D, true> {
 #define ANN_D_FOLD2 (-243)
 #define ANN_D_FOLD3 (-244)
 #define ANN_D_FOLD4 (-245)
+// D = ANN_D_FOLD4G / ANN_D_FOLD5G: rows that have NO lanes-per-row layout (more than 64 chunks that do not split evenly:
+// d = 300 float, d = 150 double): every kernel runs its any-d code (literal tree through LDS) except the selection
+// gathers, which fold 4 / 5 levels (16 / 32 leaves per lane).
+#define ANN_D_FOLD4G (-246)
+#define ANN_D_FOLD5G (-247)
 // levels of the literal tree folded into a lane for a row of d elements: halve until <= 16 values remain (0: none)
 __host__ __device__ inline int ann_fold_levels(int d) {
   int s = d, L = 0;
@@ -316,10 +321,12 @@ __host__ __device__ inline int ann_fold_levels(int d) {
 }
 template <int D>
 struct OcCode {
-  static constexpr int FOLD = D == ANN_D_FOLD2 ? 2 : D == ANN_D_FOLD3 ? 3 : D == ANN_D_FOLD4 ? 4 : 0;
-  static constexpr bool UA = D == ANN_D_UNALIGNED || FOLD > 0;
-  static constexpr int C = D < 0 ? ((-D) % 16) : 1;
-  static constexpr int OC = (D < 0 && !UA) ? ((-D) / 16) : 0;
+  static constexpr bool GEN = D == ANN_D_FOLD4G || D == ANN_D_FOLD5G;  // the any-d code paths outside the gathers
+  static constexpr int FOLD = D == ANN_D_FOLD2 ? 2 : D == ANN_D_FOLD3 ? 3 : (D == ANN_D_FOLD4 || D == ANN_D_FOLD4G) ? 4 :
+                              D == ANN_D_FOLD5G ? 5 : 0;
+  static constexpr bool UA = D == ANN_D_UNALIGNED || (FOLD > 0 && !GEN);
+  static constexpr int C = (D < 0 && !GEN && !UA) ? ((-D) % 16) : 1;  // 16-byte chunks per lane (1 in the element-wise layouts)
+  static constexpr int OC = (D < 0 && !GEN && !UA) ? ((-D) / 16) : 0;
 };
 template <int D>
 struct RowChunks<D, false> {

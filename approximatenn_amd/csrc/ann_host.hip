@@ -501,8 +501,18 @@ static int layout_code(size_t d, bool allow_oc = true) {
   // d not a multiple of the 16-byte chunk: ceil(d/VEC) lanes per row, element-wise loads, tree of length d
   if (allow_oc && d % ANN_VEC != 0 && (d + ANN_VEC - 1) / ANN_VEC >= 2 && (d + ANN_VEC - 1) / ANN_VEC <= 64) return ANN_D_UNALIGNED;
 #endif
+#ifndef ANN_NO_FOLD
+  // no lanes-per-row layout at all (d = 300 float: 75 chunks; d = 150 double): the any-d code everywhere, but the
+  // selection gathers fold 4 or 5 levels into a lane
+  if (allow_oc) {
+    const int L = ann_fold_levels((int)d);
+    if (L == 4) return ANN_D_FOLD4G;
+    if (L == 5) return ANN_D_FOLD5G;
+  }
+#endif
   return 0;
 }
+static bool layout_is_generic(int code) { return code == 0 || code == ANN_D_FOLD4G || code == ANN_D_FOLD5G; }
 #define ANN_DISPATCH_CODE(code, CALL) \
   switch (code) {                     \
     case 16: CALL(16); break;         \
@@ -528,7 +538,7 @@ static int layout_code(size_t d, bool allow_oc = true) {
     ANN_CASE_FOLD4(CALL) \
     default: CALL(0); break;          \
   }
-#define ANN_CASE_FOLD4(CALL) case ANN_D_FOLD4: CALL(ANN_D_FOLD4); break;
+#define ANN_CASE_FOLD4(CALL) case ANN_D_FOLD4: CALL(ANN_D_FOLD4); break; case ANN_D_FOLD4G: CALL(ANN_D_FOLD4G); break; case ANN_D_FOLD5G: CALL(ANN_D_FOLD5G); break;
 #ifdef USE_FLOAT
 #define ANN_CASE_1024(CALL) case 1024: CALL(1024); break;
 #else
@@ -540,7 +550,7 @@ static int layout_code(size_t d, bool allow_oc = true) {
 #define ANN_DISPATCH_D2(dval, CALL) ANN_DISPATCH_CODE(layout_code((size_t)(dval), false), CALL)
 
 static bool d_is_fast(size_t d) { return layout_code(d, false) > 0; }   // power-of-two register layout
-static bool d_needs_lds_row(size_t d) { return layout_code(d) == 0; }    // literal tree through LDS
+static bool d_needs_lds_row(size_t d) { return layout_is_generic(layout_code(d)); }    // literal tree through LDS
 
 template <typename K>
 static void allow_lds(K kernel, size_t bytes) {

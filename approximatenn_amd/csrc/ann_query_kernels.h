@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void codes_kernel(QParams P, int Q, const FT *
       for (int m = 32; m >= 1; m >>= 1) code |= __shfl_xor(code, m);
       if (lane == 0) codes[(size_t)q * P.T + t] = code;
     }
-  } else if constexpr (D < 0) {
+  } else if constexpr (D < 0 && !OcCode<D>::GEN) {
     constexpr int C = OcCode<D>::C, OC = OcCode<D>::OC;
     const OcLanes<D> ol(P.d, lane);
     const int oc = ol.oc, rpw = ol.rpw, g = ol.g, p = ol.p;
@@ -459,14 +459,11 @@ __device__ __forceinline__ void gather_select(const QParams &P, const u32 *list,
         }
       }
     }
-  } else if constexpr (D < 0) {
+  } else if constexpr (OcCode<D>::FOLD > 0) {  // the first tree levels inside a lane (host: layout_code chose this d for it)
+    const FoldPlan fp(P.d);
+    gather_fold<OcCode<D>::FOLD>(P, fp, list, cnt, alias, x, yrow, S);
+  } else if constexpr (D < 0 && !OcCode<D>::GEN) {
     constexpr int C = OcCode<D>::C, OC = OcCode<D>::OC;
-    if constexpr (OcCode<D>::FOLD > 0) {  // the first tree levels inside a lane (host: layout_code chose this d for it)
-      const FoldPlan fp(P.d);
-      gather_fold<OcCode<D>::FOLD>(P, fp, list, cnt, alias, x, yrow, S);
-      wave_lds_sync();
-      return;
-    }
     const OcLanes<D> ol(P.d, lane);
     const int oc = ol.oc, rpw = ol.rpw, g = ol.g, p = ol.p;  // lanes with !ol.valid have no row
     VT bn[C];
@@ -562,7 +559,7 @@ __device__ __forceinline__ u32 stage2_in_workgroup(const QParams &P, u32 x, int 
       const FT dist = row_reduce<D, ROW_SQDIFF>(a, b);
       if (act && p == 0) t_dist[t_slot[r]] = dist;
     }
-  } else if constexpr (D < 0) {
+  } else if constexpr (D < 0 && !OcCode<D>::GEN) {
     constexpr int C = OcCode<D>::C, OC = OcCode<D>::OC;
     const OcLanes<D> ol(P.d, lane);
     const int oc = ol.oc, rpw = ol.rpw, g = ol.g, p = ol.p;
@@ -619,7 +616,7 @@ __global__ __launch_bounds__(128) void stage2_fused_kernel(QParams P, int Q, con
   FT *yq = reinterpret_cast<FT *>(sp);  // generic d only: [d] + 2*[d]
   for (int t = threadIdx.x; t < k; t += blockDim.x) top[t] = key_make(top_dist[(size_t)x * k + t], top_id[(size_t)x * k + t]);
   if (threadIdx.x == 0) *cnt2 = 0;
-  if constexpr (D == 0)
+  if constexpr (D == 0 || OcCode<D>::GEN)
     for (int z = threadIdx.x; z < P.d; z += blockDim.x) yq[z] = y[(size_t)x * P.d + z];
   VT a[RowChunks<D>::C];
   if constexpr (D > 0) {
@@ -627,7 +624,7 @@ __global__ __launch_bounds__(128) void stage2_fused_kernel(QParams P, int Q, con
     const VT *yp = reinterpret_cast<const VT *>(y + (size_t)x * D) + (lane % L::LPR);
 #pragma unroll
     for (int c = 0; c < L::C; c++) a[c] = yp[c * L::LPR];
-  } else if constexpr (D < 0) {
+  } else if constexpr (D < 0 && !OcCode<D>::GEN) {
     const OcLanes<D> ol(P.d, lane);
 #pragma unroll
     for (int c = 0; c < OcCode<D>::C; c++) a[c] = oc_load_chunk<D, false>(y + (size_t)x * P.d, ol.p + c * ol.oc, P.d);
@@ -675,7 +672,7 @@ __global__ __launch_bounds__(256) void stage2_select_kernel(QParams P, int Q, co
 
   for (int t = threadIdx.x; t < k; t += blockDim.x) top[t] = key_make(top_dist[(size_t)x * k + t], top_id[(size_t)x * k + t]);
   if (threadIdx.x < 4) cnts[threadIdx.x] = 0;
-  if constexpr (D == 0)
+  if constexpr (D == 0 || OcCode<D>::GEN)
     for (int z = threadIdx.x; z < P.d; z += blockDim.x) yq[z] = y[(size_t)x * P.d + z];
   VT a[RowChunks<D>::C];
   if constexpr (D > 0) {
@@ -683,7 +680,7 @@ __global__ __launch_bounds__(256) void stage2_select_kernel(QParams P, int Q, co
     const VT *yp = reinterpret_cast<const VT *>(y + (size_t)x * D) + (lane % L::LPR);
 #pragma unroll
     for (int c = 0; c < L::C; c++) a[c] = yp[c * L::LPR];
-  } else if constexpr (D < 0) {
+  } else if constexpr (D < 0 && !OcCode<D>::GEN) {
     const OcLanes<D> ol(P.d, lane);
 #pragma unroll
     for (int c = 0; c < OcCode<D>::C; c++) a[c] = oc_load_chunk<D, false>(y + (size_t)x * P.d, ol.p + c * ol.oc, P.d);
@@ -840,7 +837,7 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
     qcode[i] = P.fixed ? codes[(size_t)x * P.T + i] : codes[(size_t)i * Q + x];  // Q2: read layout [try][query]
   }
   if (threadIdx.x < 4) cnts[threadIdx.x] = 0;
-  if constexpr (D == 0)
+  if constexpr (D == 0 || OcCode<D>::GEN)
     for (int z = threadIdx.x; z < P.d; z += blockDim.x) yq[z] = y[(size_t)x * P.d + z];
   __syncthreads();
 
@@ -857,7 +854,7 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
     const VT *yp = reinterpret_cast<const VT *>(y + (size_t)x * D) + (lane % L::LPR);
 #pragma unroll
     for (int c = 0; c < L::C; c++) a[c] = yp[c * L::LPR];
-  } else if constexpr (D < 0) {
+  } else if constexpr (D < 0 && !OcCode<D>::GEN) {
     const OcLanes<D> ol(P.d, lane);
 #pragma unroll
     for (int c = 0; c < OcCode<D>::C; c++) a[c] = oc_load_chunk<D, false>(y + (size_t)x * P.d, ol.p + c * ol.oc, P.d);
@@ -1319,7 +1316,7 @@ __global__ __launch_bounds__(256) void row_dists_kernel(QParams P, int Q, const 
       tries[i] = P.tries[i];
       qcode[i] = codes[(size_t)i * Q + x];
     }
-  if constexpr (D == 0)
+  if constexpr (D == 0 || OcCode<D>::GEN)
     for (int z = threadIdx.x; z < P.d; z += blockDim.x) yq[z] = y[(size_t)x * P.d + z];
   VT a[RowChunks<D>::C];
   if constexpr (D > 0) {
@@ -1327,7 +1324,7 @@ __global__ __launch_bounds__(256) void row_dists_kernel(QParams P, int Q, const 
     const VT *yp = reinterpret_cast<const VT *>(y + (size_t)x * D) + (lane % L::LPR);
 #pragma unroll
     for (int c = 0; c < L::C; c++) a[c] = yp[c * L::LPR];
-  } else if constexpr (D < 0) {
+  } else if constexpr (D < 0 && !OcCode<D>::GEN) {
     const OcLanes<D> ol(P.d, lane);
 #pragma unroll
     for (int c = 0; c < OcCode<D>::C; c++) a[c] = oc_load_chunk<D, false>(y + (size_t)x * P.d, ol.p + c * ol.oc, P.d);
@@ -1387,7 +1384,7 @@ __global__ __launch_bounds__(256) void row_dists_kernel(QParams P, int Q, const 
         const FT dist = row_reduce<D, ROW_SQDIFF>(a, b);
         if (act && p == 0) dist_row[lslot[r]] = dist;
       }
-    } else if constexpr (D < 0) {
+    } else if constexpr (D < 0 && !OcCode<D>::GEN) {
       constexpr int C = OcCode<D>::C, OC = OcCode<D>::OC;
       const OcLanes<D> ol(P.d, lane);
       const int oc = ol.oc, rpw = ol.rpw, g = ol.g, p = ol.p;

@@ -89,7 +89,7 @@ def test_bucket_kernel_member_groups_and_two_key_lanes(prec, d, k, group, monkey
 
 
 @pytest.mark.parametrize("prec,d", [("f32", 36), ("f32", 50), ("f32", 77), ("f32", 100), ("f64", 100), ("f32", 150),
-                                    ("f32", 250), ("f64", 72), ("f64", 77), ("f32", 200), ("f32", 300)])
+                                    ("f32", 250), ("f64", 72), ("f64", 77), ("f32", 200), ("f32", 300), ("f64", 150), ("f32", 1000), ("f64", 300)])
 def test_row_lengths_folded_and_neighbours(prec, d):
     """Row lengths of the folded layouts (2, 3 or -- unaligned only -- 4 tree levels inside a lane), with odd levels at
     different depths (77: levels 1 and 3; 100: level 3; 150: level 2; 250: levels 2 and 4), and their neighbours that keep
