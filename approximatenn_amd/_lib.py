@@ -6,6 +6,7 @@ loudly (ImportError here, "No GPU found." + exit(1) from gpu_init() in the libra
 import ctypes as C
 import os
 import subprocess
+import threading
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 _libs = {}
@@ -112,10 +113,16 @@ def load(prec="f32"):
     lib.annhip_stage2_rows_list.argtypes = [vp, sz, vp, C.c_int, u32p, sz, u32p, vp, u32p, vp]
     lib.annhip_exact_select.argtypes = [vp, C.c_int, sz, u32p, vp, u32p, u32p, vp]
     lib.annhip_recall_ranks.argtypes = [sz, sz, sz, vp, sz, vp, vp, C.c_int, vp]
+    lib.annhip_checksum_dev.restype = C.c_ulonglong
+    lib.annhip_checksum_dev.argtypes = [vp, sz, vp]
+    lib.annhip_index_checksum.restype = C.c_ulonglong
+    lib.annhip_index_checksum.argtypes = [vp]
     lib.annhip_profile.argtypes = [vp, C.c_int]
     lib.annhip_stats.argtypes = [vp, C.POINTER(C.c_double * 8), C.c_int]
     lib.annhip_stage_ms.argtypes = [vp, C.POINTER(C.c_double * 6)]
     lib.annhip_cache_clear.argtypes = []
+    lib.annhip_fingerprint_ms.restype = C.c_double
+    lib.annhip_fingerprint_ms.argtypes = [C.POINTER(SaveT), vp, C.c_int]
     lib.annhip_host_profile.argtypes = [C.c_int]
     lib.annhip_host_stats.restype = C.c_int
     lib.annhip_host_stats.argtypes = [C.POINTER(SaveT), C.POINTER(C.c_double * 8), C.c_int]
@@ -143,7 +150,66 @@ EXPORTED = ["gpu_init", "gpu_cleanup", "register_cleanup", "query_gpu", "precomp
             "annhip_precomp_try", "annhip_precomp_merge", "annhip_precomp_graph", "annhip_precomp_finish", "annhip_query", "annhip_workspace_create", "annhip_workspace_destroy", "annhip_query_on", "annhip_stream_open", "annhip_stream_submit", "annhip_stream_collect", "annhip_stream_close",
             "annhip_key_bytes", "annhip_stream_create_reserving", "annhip_stream_destroy", "annhip_sh_codes", "annhip_sh_stage1", "annhip_sh_merge_finalize", "annhip_sh_exact1_begin", "annhip_sh_exact1_end", "annhip_sh_stage2",
             "annhip_sh_final", "annhip_stage1_rows", "annhip_stage2_rows_list", "annhip_exact_select",
-            "annhip_recall_ranks", "annhip_profile", "annhip_stats", "annhip_stage_ms",
-            "annhip_cache_clear", "annhip_cache_drop", "annhip_cache_size", "annhip_reload_env",
+            "annhip_recall_ranks", "annhip_checksum_dev", "annhip_index_checksum", "annhip_profile", "annhip_stats", "annhip_stage_ms",
+            "annhip_cache_clear", "annhip_fingerprint_ms", "annhip_cache_drop", "annhip_cache_size", "annhip_reload_env",
             "annhip_synth_randnorm", "annhip_synth_reset", "annhip_host_profile", "annhip_host_stats"]
 DISPATCH_EXPORTED = ["precomp", "query", "free_save"]
+
+
+# ---- the caller's libc random() stream (the workload's data and precomp's rotations are drawn from it) ----
+_libc = C.CDLL("libc.so.6")
+_libc.initstate.restype = C.c_void_p
+_libc.initstate.argtypes = [C.c_uint, C.c_void_p, C.c_size_t]
+_libc.setstate.restype = C.c_void_p
+_libc.setstate.argtypes = [C.c_void_p]
+_RAND_WORDS = (1, 8, 16, 32, 64)   # glibc random_r.c: state words (degree + 1) of TYPE_0..TYPE_4; word 0 = rear*5 + type
+_restored = []                      # state buffers handed to setstate() must outlive the call
+
+
+_park_lock = threading.Lock()
+_park_depth = 0
+_park_old = None
+
+
+class park_random:
+    """Context manager: libc random() draws made inside (the HIP runtime draws while it initialises) do not touch the
+    caller's stream.  The library's own entry points do the same (RandGuard, csrc/ann_host.hip).  Nestable, and several
+    host threads may be inside at once (rank threads of the tests): only the outermost one swaps the state."""
+
+    def __enter__(self):
+        global _park_depth, _park_old
+        with _park_lock:
+            if _park_depth == 0:
+                # 128 bytes = the generator type of libc's default state (TYPE_3): a thread that seeds and draws while
+                # another one holds the park (rank threads of the tests) gets the sequence it would get unparked
+                buf = C.create_string_buffer(128)
+                _restored.append(buf)               # a state buffer glibc has seen is never freed
+                _park_old = _libc.initstate(1, buf, 128)
+            _park_depth += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _park_depth
+        with _park_lock:
+            _park_depth -= 1
+            if _park_depth == 0:
+                _libc.setstate(_park_old)
+
+
+def random_state_snapshot():
+    """The complete state of the process's current libc random() stream as bytes (glibc layout: switching states makes
+    glibc store the rear pointer into word 0 of the state it leaves).  random_state_restore() on ANY process continues
+    the stream from exactly there -- how one rank hands the benchmark's stream to the others."""
+    scratch = C.create_string_buffer(256)
+    cur = _libc.initstate(1, scratch, 256)          # leaves the current state; its word 0 now holds rear*5 + type
+    word0 = C.cast(cur, C.POINTER(C.c_int32))[0]
+    nbytes = 4 * _RAND_WORDS[word0 % 5]
+    snap = C.string_at(cur, nbytes)
+    _libc.setstate(cur)
+    return snap
+
+
+def random_state_restore(snap):
+    buf = C.create_string_buffer(bytes(snap), len(snap))
+    _restored.append(buf)
+    _libc.setstate(buf)

@@ -228,6 +228,12 @@ def recall_ranks(points, y, guess, self_exclude=False):
     return ranks
 
 
+def checksum(t, prec="f32"):
+    """annhip_checksum_dev: 64-bit content checksum of a contiguous torch device tensor."""
+    assert t.is_cuda and t.is_contiguous()
+    return int(_lib.load(prec).annhip_checksum_dev(t.data_ptr(), t.numel() * t.element_size(), None))
+
+
 def recall_summary(ranks, k):
     """The three numbers /root/reference/test_correctness.c:131-139 prints, from a rank tensor [Q,k]:
     average index score (mean rank excess per neighbour), probability correct (rank < k), max index score / k."""
@@ -330,6 +336,10 @@ class Index:
     def host_stream(self, max_ycnt, lanes=3):
         """annhip_stream_open: pipeline for host-resident (numpy) batches; see HostStream."""
         return HostStream(self, max_ycnt, lanes)
+
+    def checksum(self):
+        """annhip_index_checksum: 64-bit checksum of everything a query reads except the point rows."""
+        return int(self.lib.annhip_index_checksum(self.h))
 
     def profile(self, on=True):
         self.lib.annhip_profile(self.h, int(on))

@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <algorithm>
 #include <limits>
@@ -18,6 +19,7 @@
 #include "../../include/algg.h"
 #include "../../include/ann_hip.h"
 #include "../../include/gpu_comp.h"
+#include "ann_hostpool.h"
 #include "ann_precomp_kernels.h"
 #include "ann_query_kernels.h"
 #include "ann_recall_kernels.h"
@@ -186,6 +188,24 @@ struct DevBuf {  // grow-only device workspace
   }
 };
 
+struct PinBuf {  // grow-only pinned host memory
+  void *p = NULL;
+  size_t cap = 0;
+  void *need(size_t bytes) {
+    if (bytes > cap) {
+      if (p) HIPCHECK(hipHostFree(p));
+      size_t want = bytes + bytes / 8 + 256;
+      HIPCHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
+      cap = want;
+    }
+    return p;
+  }
+  void release() {
+    if (p) HIPCHECK(hipHostFree(p));
+    p = NULL, cap = 0;
+  }
+};
+
 template <typename T>
 static T *dev_alloc(size_t count) {
   void *p = NULL;
@@ -238,6 +258,7 @@ struct annhip_index {
   hipStream_t stream = 0;
   annhip_workspace ws;           // default workspace (annhip_query, staged calls)
   DevBuf io_y, io_ids, io_dist;  // query_gpu's staging of host inputs/outputs, reused between calls
+  PinBuf io_y_pin, io_out_pin;   // ... and their pinned host-side bounce buffers
   unsigned long long *d_rows = NULL;  // [0] stage-1 gathered rows, [2] exact-path queries, [8..8+512) rows kernels (64 padded shards)
   // measurement
   bool profile = false;
@@ -424,6 +445,7 @@ extern "C" void annhip_index_destroy(annhip_index *ix) {
   if (ix->d_rows) HIPCHECK(hipFree(ix->d_rows));
   ix->ws.release();
   ix->io_y.release(), ix->io_ids.release(), ix->io_dist.release();
+  ix->io_y_pin.release(), ix->io_out_pin.release();
   for (auto &e : ix->ev_used) (void)hipEventDestroy(e.a), (void)hipEventDestroy(e.b);
   for (auto &e : ix->ev_free) (void)hipEventDestroy(e.a), (void)hipEventDestroy(e.b);
   for (hipEvent_t e : ix->seg_free) (void)hipEventDestroy(e);
@@ -946,8 +968,10 @@ static size_t codes_needed(const annhip_index *ix, size_t Q) {
 }
 
 // ----------------------------------------------------------------------------- query
+// codes_ready: ws.codes already holds the hash codes of this batch (query_gpu computes them chunk by chunk while the
+// batch is still arriving over PCIe)
 static long query_impl(annhip_index *ix, annhip_workspace &ws, hipStream_t s, size_t Q, const ftype *y_dev, int alias,
-                       int mode, size_t *ids_dev, ftype *dists_dev) {
+                       int mode, size_t *ids_dev, ftype *dists_dev, bool codes_ready = false) {
   if (!Q) return 0;
   if (Q >= 0x7FFFFFFFull / (size_t)(ix->T > 0 ? ix->T : 1)) die("query batch too large");
   const QParams P = make_params(ix);
@@ -959,7 +983,7 @@ static long query_impl(annhip_index *ix, annhip_workspace &ws, hipStream_t s, si
   std::vector<hipEvent_t> marks_store, *marks = ix->profile ? &marks_store : NULL;
   seg_mark(ix, marks, s);
   u32 *codes = (u32 *)ws.codes.need(sizeof(u32) * Q * P.T);
-  launch_codes(P, codes_needed(ix, Q), y, codes, s);
+  if (!codes_ready) launch_codes(P, codes_needed(ix, Q), y, codes, s);
   seg_mark(ix, marks, s);
   u32 *top_i = (u32 *)ws.top_i.need(sizeof(u32) * Q * k);
   FT *top_d = (FT *)ws.top_d.need(sizeof(FT) * Q * k);
@@ -1339,6 +1363,69 @@ extern "C" void annhip_stage2_rows_list(annhip_index *ix, size_t Q, const ftype 
   launch_rows<MODE_GRAPH>(P, Q, reinterpret_cast<const FT *>(y_dev), alias, NULL, qidx_dev, 0, nq, P.Lc2, top_id_dev,
                           reinterpret_cast<const FT *>(top_dist_dev), ids_dev, reinterpret_cast<FT *>(dist_dev),
                           ix->profile ? ix->d_rows + 8 : NULL, ix->stream);
+}
+
+// ---- content checksums (multi-GPU hosts prove with them that every rank holds the same index and the same batch;
+// bench.py all-reduces them with MIN and MAX).  Order-sensitive per word, commutative across words, so the result does
+// not depend on the launch geometry: sum over i of mix(word_i, i).
+__global__ void checksum_kernel(size_t nwords, const u32 *__restrict__ w, size_t tail_bytes, unsigned long long *out) {
+  unsigned long long acc = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned long long v = ((unsigned long long)w[i] << 32 | (u32)i) ^ ((unsigned long long)(i >> 32) * 0x9E3779B97F4A7C15ull);
+    v *= 0xFF51AFD7ED558CCDull;
+    v ^= v >> 29;
+    v *= 0xC4CEB9FE1A85EC53ull;
+    acc += v ^ (v >> 32);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && tail_bytes) {  // the last 1..3 bytes of a length that is no multiple of 4
+    const unsigned char *b = reinterpret_cast<const unsigned char *>(w + nwords);
+    u32 t = 0;
+    for (size_t j = 0; j < tail_bytes; j++) t |= (u32)b[j] << (8 * j);
+    acc += ((unsigned long long)t + 1) * 0xD6E8FEB86659FD93ull + nwords;
+  }
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) acc += __shfl_xor(acc, s);
+  if (lane_id() == 0) atomicAdd(out, acc);
+}
+
+static unsigned long long checksum_dev(const void *p, size_t nbytes, unsigned long long *d_acc, hipStream_t s) {
+  if ((uintptr_t)p % 4) die("annhip_checksum_dev: pointer must be 4-byte aligned");
+  HIPCHECK(hipMemsetAsync(d_acc, 0, sizeof(unsigned long long), s));
+  const size_t nwords = nbytes / 4;
+  checksum_kernel<<<grid_for(nwords ? nwords : 1, 256, 4096), 256, 0, s>>>(nwords, (const u32 *)p, nbytes % 4, d_acc);
+  HIPCHECK(hipGetLastError());
+  unsigned long long h = 0;
+  HIPCHECK(hipMemcpyAsync(&h, d_acc, sizeof h, hipMemcpyDeviceToHost, s));
+  HIPCHECK(hipStreamSynchronize(s));
+  return h ^ (nbytes * 0x9E3779B97F4A7C15ull);
+}
+
+extern "C" unsigned long long annhip_checksum_dev(const void *dev_ptr, size_t nbytes, void *hip_stream) {
+  RandGuard keep_callers_stream;
+  gpu_init();
+  unsigned long long *acc = dev_alloc<unsigned long long>(1);
+  const unsigned long long h = checksum_dev(dev_ptr, nbytes, acc, (hipStream_t)hip_stream);
+  HIPCHECK(hipFree(acc));
+  return h;
+}
+
+// everything a query reads except the point rows: geometry, bucket tables, graph, means, projection rows
+extern "C" unsigned long long annhip_index_checksum(annhip_index *ix) {
+  RandGuard keep_callers_stream;
+  unsigned long long *acc = dev_alloc<unsigned long long>(1);
+  hipStream_t s = ix->stream;
+  const size_t nb = (size_t)1 << ix->ds;
+  unsigned long long h = ix->n * 0x100000001B3ull ^ ix->k << 40 ^ ix->d << 20 ^ ix->ds << 8 ^ (size_t)ix->T;
+  auto fold = [&](unsigned long long v) { h = (h ^ v) * 0xFF51AFD7ED558CCDull, h ^= h >> 31; };
+  for (int t = 0; t < ix->T; t++) {
+    fold(ix->h_tries[t].pm);
+    fold(checksum_dev(ix->d_tabs[t], sizeof(u32) * nb * ix->h_tries[t].pm, acc, s));
+  }
+  fold(checksum_dev(ix->d_graph, sizeof(u32) * ix->n * ix->k, acc, s));
+  fold(checksum_dev(ix->d_means, sizeof(FT) * ix->d, acc, s));
+  fold(checksum_dev(ix->d_bases, sizeof(FT) * (size_t)ix->T * ix->ds * ix->d, acc, s));
+  HIPCHECK(hipFree(acc));
+  return h;
 }
 
 extern "C" void annhip_profile(annhip_index *ix, int profile) { ix->profile = profile != 0; }
@@ -1902,6 +1989,24 @@ struct FpHash {  // four independent multiply lanes over 64-bit words: a few GB/
   u64 done() const { return (h[0] * 3 + h[1] * 5 + h[2] * 7 + h[3] * 11) ^ (u64)cnt; }
 };
 
+// strict mode: the full content, hashed in 4 MB blocks by the host pool (block hashes combined in order).  One core
+// hashes ~10 GB/s; the ~8 GB of a cfg3 index (points 5.1 GB, size_t tables 2.3 GB, graph 0.8 GB) take ~1 s on one
+// thread and are memory-bound on the pool.
+static u64 hash_region(const void *p, size_t nbytes) {
+  const size_t BL = (size_t)4 << 20, nblocks = (nbytes + BL - 1) / BL;
+  std::vector<u64> part(nblocks ? nblocks : 1, 0);
+  HostPool::get().run(nblocks, [&](size_t b) {
+    FpHash H;
+    const size_t a = b * BL;
+    H.bytes((const char *)p + a, std::min(BL, nbytes - a));
+    part[b] = H.done();
+  });
+  FpHash H;
+  H.bytes(part.data(), sizeof(u64) * nblocks);
+  H.word(nbytes);
+  return H.done();
+}
+
 static u64 fingerprint(const save_t *sv, const ftype *points) {
   const bool full = env().cache_mode == 1;
   const size_t nb = (size_t)1 << sv->d_short;
@@ -1910,15 +2015,29 @@ static u64 fingerprint(const save_t *sv, const ftype *points) {
   H.bytes(sv->row_means, sizeof(ftype) * sv->d_long);
   H.bytes(sv->bases, sizeof(ftype) * (size_t)sv->tries * sv->d_short * sv->d_long);
   if (full) {
-    H.bytes(points, sizeof(ftype) * sv->n * sv->d_long);
-    H.bytes(sv->graph, sizeof(size_t) * sv->n * sv->k);
-    for (int t = 0; t < sv->tries; t++) H.bytes(sv->which_par[t], sizeof(size_t) * nb * sv->par_maxes[t]);
+    H.word(hash_region(points, sizeof(ftype) * sv->n * sv->d_long));
+    H.word(hash_region(sv->graph, sizeof(size_t) * sv->n * sv->k));
+    for (int t = 0; t < sv->tries; t++) H.word(hash_region(sv->which_par[t], sizeof(size_t) * nb * sv->par_maxes[t]));
   } else {
     H.sampled(points, sv->n * sv->d_long);
     H.sampled(sv->graph, sv->n * sv->k);
     for (int t = 0; t < sv->tries; t++) H.sampled(sv->which_par[t], nb * sv->par_maxes[t]);
   }
   return H.done();
+}
+
+// ANN_HIP_CACHE=strict costs this much per query() call: exported so that harnesses can print it (time_results -F)
+extern "C" double annhip_fingerprint_ms(const save_t *save, const ftype *points, int strict) {
+  const int keep = g_env.loaded ? g_env.cache_mode : 0;
+  env();
+  g_env.cache_mode = strict ? 1 : 0;
+  struct timespec a, b;
+  clock_gettime(CLOCK_MONOTONIC, &a);
+  volatile u64 fp = fingerprint(save, points);
+  (void)fp;
+  clock_gettime(CLOCK_MONOTONIC, &b);
+  g_env.cache_mode = keep;
+  return (b.tv_sec - a.tv_sec) * 1e3 + (b.tv_nsec - a.tv_nsec) * 1e-6;
 }
 
 static void cache_clear() {
@@ -2012,14 +2131,34 @@ extern "C" size_t *query_gpu(const save_t *save, const ftype *points, size_t ycn
     if (!resident) annhip_index_destroy(ix);
     return result;
   }
+  // The batch arrives in pageable host memory (ann.h:61-62).  It is copied into a pinned bounce buffer by the host
+  // pool and sent in pieces: while piece i+1 is being copied on the host, piece i crosses PCIe and its queries are
+  // hashed (the codes are per query; only stage 1 needs all of them, Q2).  Results come back through one pinned buffer.
   FT *y_dev = (FT *)ix->io_y.need(sizeof(FT) * ycnt * d);
   size_t *ids_dev = (size_t *)ix->io_ids.need(sizeof(size_t) * ycnt * k);
   FT *dist_dev = (FT *)ix->io_dist.need(sizeof(FT) * ycnt * k);
-  HIPCHECK(hipMemcpy(y_dev, y, sizeof(FT) * ycnt * d, hipMemcpyHostToDevice));
-  annhip_query(ix, ycnt, y_dev, y == points, 0, ids_dev, dist_dev);
-  HIPCHECK(hipStreamSynchronize(ix->stream));
-  HIPCHECK(hipMemcpy(result, ids_dev, sizeof(size_t) * ycnt * k, hipMemcpyDeviceToHost));
-  if (dists_o) HIPCHECK(hipMemcpy(*dists_o, dist_dev, sizeof(FT) * ycnt * k, hipMemcpyDeviceToHost));
+  char *y_pin = (char *)ix->io_y_pin.need(sizeof(FT) * ycnt * d);
+  hipStream_t s = ix->stream;
+  const QParams P = make_params(ix);
+  const size_t row = sizeof(FT) * d, hashed = codes_needed(ix, ycnt);
+  const size_t pieces = std::max<size_t>(1, std::min<size_t>(8, ycnt * row >> 20));  // >= 1 MB each
+  const size_t per = (ycnt + pieces - 1) / pieces;
+  u32 *codes = (u32 *)ix->ws.codes.need(sizeof(u32) * ycnt * P.T);
+  for (size_t q0 = 0; q0 < ycnt; q0 += per) {
+    const size_t nq = std::min(per, ycnt - q0);
+    HostPool::get().copy(y_pin + q0 * row, (const char *)y + q0 * row, nq * row);
+    HIPCHECK(hipMemcpyAsync((char *)y_dev + q0 * row, y_pin + q0 * row, nq * row, hipMemcpyHostToDevice, s));
+    if (q0 < hashed) launch_codes(P, std::min(nq, hashed - q0), y_dev + q0 * d, codes + q0 * P.T, s);
+  }
+  query_impl(ix, ix->ws, s, ycnt, reinterpret_cast<const ftype *>(y_dev), y == points, 0, ids_dev,
+             reinterpret_cast<ftype *>(dist_dev), true);
+  const size_t ib = sizeof(size_t) * ycnt * k, db = dists_o ? sizeof(FT) * ycnt * k : 0;
+  char *out_pin = (char *)ix->io_out_pin.need(ib + db);
+  HIPCHECK(hipMemcpyAsync(out_pin, ids_dev, ib, hipMemcpyDeviceToHost, s));
+  if (db) HIPCHECK(hipMemcpyAsync(out_pin + ib, dist_dev, db, hipMemcpyDeviceToHost, s));
+  HIPCHECK(hipStreamSynchronize(s));
+  HostPool::get().copy(result, out_pin, ib);
+  if (db) HostPool::get().copy(*dists_o, out_pin + ib, db);
   if (!resident) annhip_index_destroy(ix);
   return result;
 }

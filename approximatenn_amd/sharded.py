@@ -229,15 +229,23 @@ class ShardedQuery:
         if want in ("alltoall", "allgather"):
             return want
         ok = 1
-        try:  # a tiny all-to-all on the backend's native tensors; an unsupported op raises on every rank alike
-            dev = "cpu" if (self._via_cpu or not torch.cuda.is_available()) else torch.device("cuda", torch.cuda.current_device())
-            a = torch.arange(self.world, dtype=torch.int64, device=dev) + 100 * self.rank
-            b = torch.empty_like(a)
+        dev = "cpu" if (self._via_cpu or not torch.cuda.is_available()) else torch.device("cuda", torch.cuda.current_device())
+        a = torch.arange(self.world, dtype=torch.int64, device=dev) + 100 * self.rank
+        b = torch.empty_like(a)
+        try:  # a tiny all-to-all on the backend's native tensors.  ONLY "this backend has no such op" -- raised before
+            # anything is enqueued, on every rank alike -- selects the fallback; any other failure (out of memory, a
+            # communicator error) is rank-local: the peers are inside the all-to-all, so this rank must die, not go on
+            # to a different collective.
             self.dist.all_to_all_single(b, a, group=self.group)
-            if b.cpu().tolist() != [100 * g + self.rank for g in range(self.world)]:
-                ok = 0
-        except Exception:  # noqa: BLE001
+        except NotImplementedError:
             ok = 0
+        except RuntimeError as err:
+            msg = str(err).lower()
+            if not ("not supported" in msg or "unsupported" in msg or "does not support" in msg or "not implemented" in msg):
+                raise
+            ok = 0
+        if ok and b.cpu().tolist() != [100 * g + self.rank for g in range(self.world)]:
+            raise RuntimeError("all_to_all_single delivered wrong data on rank %d" % self.rank)
         flag = torch.tensor([ok], dtype=torch.int32, device=dev)
         self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN, group=self.group)   # every rank takes the same branch
         return "alltoall" if int(flag.cpu()[0]) == 1 else "allgather"
@@ -371,12 +379,17 @@ class ShardedQuery:
             L.event.synchronize()
         nf = int(L.head_host[0])              # flagged queries the device-driven exact path had no room for; the same
         self.last_exact = int(L.head_host[1])  # on every rank.  [1] = all flagged queries of the batch
+        Q, G, qs = L.Q, self.world, L.qs
+        # fresh result tensors (the lane is re-used), allocated OUTSIDE the lane's stream context: they belong to the
+        # caller's stream, which waits for the lane below -- memory the caller frees can then never be handed out again
+        # while this lane's stream still writes it
+        ids = torch.empty((G * qs, e.k), dtype=torch.int64, device=L.pack_all.device)
+        dd = torch.empty((G * qs, e.k), dtype=e.ft, device=L.pack_all.device)
+        if L.stream is not None:
+            L.stream.wait_stream(torch.cuda.current_stream(L.y.device))   # ... and not before the caller's earlier work
         with e.use(L.stream):
-            Q, G, qs = L.Q, self.world, L.qs
             packed_d = L.pack_all[:, : L.nb_d].view(e.ft)                               # [G, qs*k]
             packed_i = L.pack_all[:, L.nb_d: L.nb_d + L.nb_i].view(torch.int32)
-            ids = torch.empty((G * qs, e.k), dtype=torch.int64, device=L.pack_all.device)   # fresh: the lane is re-used
-            dd = torch.empty((G * qs, e.k), dtype=e.ft, device=L.pack_all.device)
             if nf:                                                   # rare: the repair patches rows of out_i / out_d
                 L.out_d.view(G, qs * e.k).copy_(packed_d)
                 L.out_i.view(G, qs * e.k).copy_(packed_i)
@@ -410,14 +423,28 @@ class ShardedQuery:
         """y: [Q,d] (identical on every rank).  Returns (ids int64 [Q,k], squared distances [Q,k])."""
         return self.collect(self.submit(y, alias))
 
+    def close(self):
+        """Release the CU-masked gather streams (annhip_stream_create_reserving); the object is unusable afterwards."""
+        if any(L.busy for L in self._lanes):
+            raise RuntimeError("close() with batches in flight")
+        for cus, st in list(self._gather_streams.items()):
+            if cus > 0 and isinstance(st, torch.cuda.ExternalStream):
+                st.synchronize()
+                self.eng.lib.annhip_stream_destroy(st.cuda_stream)
+        self._gather_streams = {}
+        self._lanes = []
+
     # ------------------------------------------------------------------ scheduling knobs, measured in place
     # How the small kernels and the RCCL kernels of one batch get compute units beside the saturating gather of the next
     # one depends on the machine state (ranks, RCCL channel count, batch size): nothing of it changes a result bit, so it
     # is measured, not guessed.
     # Candidates: (lanes in use, two-half issue, CUs the gathers leave free, launches per gather).
-    TUNE_CANDIDATES = ((3, True, 0, 1), (3, False, 0, 1), (2, False, 0, 1), (3, True, 0, 4), (3, False, 0, 4), (2, False, 0, 4),
-                       (3, True, 0, 8), (3, False, 0, 8), (3, True, 8, 1), (3, False, 8, 1), (2, False, 8, 1), (3, False, 8, 4),
-                       (1, False, 0, 1))
+    # Candidates: (lanes in use, two-half issue, CUs the gathers leave free, launches per gather).  The first one is the
+    # PINNED default: what every job runs unless a measurement inside its time budget finds something faster.  The
+    # CU-masked candidates (hipExtStreamCreateWithCUMask) are opt-in: they only ever won the two-lane case.
+    PINNED = (3, True, 0, 1)
+    TUNE_CANDIDATES = (PINNED, (3, False, 0, 1), (2, False, 0, 1), (3, True, 0, 4), (3, False, 0, 4), (1, False, 0, 1))
+    TUNE_CANDIDATES_MASKED = ((3, True, 8, 1), (3, False, 8, 1), (2, False, 8, 1))
 
     def pump(self, ys, alias=False):
         """Pipelined loop over the batches ys with `depth` batches in flight; returns the list of results."""
@@ -437,17 +464,45 @@ class ShardedQuery:
         self.pieces = max(1, int(pieces))
         self.eng.set_gather_pieces(self.pieces)
 
-    def autotune(self, y, alias=False, batches=8, candidates=None):
-        """Time `batches` pipelined batches of y under each candidate setting (after 3 untimed ones), take the MAX over
-        the ranks of each time, keep the fastest: every rank ends with the same setting, which the collectives' issue
-        order requires.  Returns {"depth", "split", "reserve_cus", "pieces", "ms_per_batch", "table"}; also kept in self.tuned."""
+    def _agreed_max(self, value, like):
+        """MAX over the ranks of a host float (one tiny all-reduce; every rank gets the same number)."""
+        if not self.dist:
+            return float(value)
+        dev = "cpu" if (self._via_cpu or not like.is_cuda) else like.device
+        t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return float(t.cpu()[0])
+
+    def autotune(self, y, alias=False, batches=8, candidates=None, budget_s=20.0):
+        """Start from the PINNED schedule; then, while the wall-clock budget lasts, time `batches` pipelined batches of y
+        under each further candidate (after 3 untimed ones) and keep the fastest.  Every decision -- a candidate's time, and
+        whether there is budget left for the next one -- is the MAX over the ranks (all-reduce), so every rank times
+        the same candidates and ends with the same setting, which the collectives' issue order requires; a candidate
+        that cannot be set up on some rank (CU-masked stream refused) counts as infinitely slow on all of them.
+        Returns {"depth", "split", "reserve_cus", "pieces", "ms_per_batch", "table", ...}; also kept in self.tuned."""
         import time
         cands = [c for c in (candidates or self.TUNE_CANDIDATES) if c[0] <= len(self._lanes)]
+        if not cands:
+            cands = [(len(self._lanes), True, 0, 1)]
         sync = (lambda: torch.cuda.synchronize(y.device)) if y.is_cuda else (lambda: None)
-        table = []
+        t_start = time.perf_counter()
         self.configure(len(self._lanes), True, 0, 1)
         self.pump([y] * (len(self._lanes) + 1), alias)        # every lane's buffers and streams exist before anything is timed
-        for c in cands:
+        table, stopped = [], None
+        for i, c in enumerate(cands):
+            if i > 0 and self._agreed_max(time.perf_counter() - t_start, y) > budget_s:
+                stopped = "budget of %.0f s used up after %d of %d candidates" % (budget_s, i, len(cands))
+                break
+            ok = 1.0
+            if c[2] > 0 and y.is_cuda and c[2] not in self._gather_streams:
+                st = self.eng.new_stream(y.device, reserve_cus=c[2])
+                if isinstance(st, torch.cuda.ExternalStream):
+                    self._gather_streams[c[2]] = st
+                else:
+                    ok = 0.0
+            if self._agreed_max(1.0 - ok, y) > 0:             # some rank cannot run this candidate: nobody does
+                table.append(float("inf"))
+                continue
             self.configure(*c)
             self.pump([y] * 3, alias)
             sync()
@@ -456,20 +511,39 @@ class ShardedQuery:
             t0 = time.perf_counter()
             self.pump([y] * batches, alias)
             sync()
-            table.append((time.perf_counter() - t0) * 1e3 / batches)
-        t = torch.tensor(table, dtype=torch.float64)
-        if self.dist:
-            dev = "cpu" if (self._via_cpu or not y.is_cuda) else y.device
-            t = -t.to(dev)
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)     # = MAX of the times
-            t = -t.cpu()
-        best = int(torch.argmin(t))
+            table.append(self._agreed_max((time.perf_counter() - t0) * 1e3 / batches, y))
+        best = min(range(len(table)), key=lambda j: table[j])
         self.configure(*cands[best])
         self.tuned = {"depth": self.depth, "split": self.split, "reserve_cus": self.reserve_cus, "pieces": self.pieces,
-                      "ms_per_batch": round(float(t[best]), 4),
-                      "table": [{"depth": c[0], "split": c[1], "reserve_cus": c[2], "pieces": c[3], "ms": round(float(v), 4)}
-                                for c, v in zip(cands, t.tolist())]}
+                      "ms_per_batch": round(table[best], 4), "pinned_ms_per_batch": round(table[0], 4),
+                      "tune_s": round(time.perf_counter() - t_start, 2),
+                      "table": [{"depth": c[0], "split": c[1], "reserve_cus": c[2], "pieces": c[3],
+                                 "ms": (round(v, 4) if v != float("inf") else None)} for c, v in zip(cands, table)]}
+        if stopped:
+            self.tuned["stopped"] = stopped
         return self.tuned
+
+
+def same_everywhere(dist, values, what="values", group=None, device="cpu"):
+    """All ranks must hold the same 64-bit `values` (checksums of the index, of a batch ...): MIN and MAX all-reduce;
+    raises SystemExit(3) ON EVERY RANK when they differ -- a rank that went on with other inputs would return wrong
+    answers silently or leave its peers in mismatched collectives."""
+    v = [int(x) & 0xFFFFFFFFFFFFFFFF for x in values]
+    if dist is None or not dist.is_initialized():
+        return v
+    # split into 32-bit halves: exact in int64 whatever the backend's integer reduction does with the sign bit
+    parts = [h for x in v for h in (x >> 32, x & 0xFFFFFFFF)]
+    lo = torch.tensor(parts, dtype=torch.int64, device=device)
+    hi = lo.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    if not torch.equal(lo.cpu(), hi.cpu()):
+        import sys
+        sys.stderr.write("approximatenn_amd: rank %d: %s differ between the ranks (mine: %s)\n"
+                         % (dist.get_rank(group), what, ["%016x" % x for x in v]))
+        sys.stderr.flush()
+        raise SystemExit(3)
+    return v
 
 
 def precomp_sharded(points, k, tries=10, rots_before=6, rot_len_before=1, rots_after=1, rot_len_after=1, dist=None,
@@ -500,6 +574,19 @@ def precomp_sharded(points, k, tries=10, rots_before=6, rot_len_before=1, rots_a
         _begin_hook()
     h = lib.annhip_precomp_begin(n, k, d, points.data_ptr(), 1, tries, rots_before, rot_len_before, rots_after,
                                  rot_len_after, rank, world)
+    # annhip_precomp_begin has made every draw this build takes from the caller's random() stream.  From here on torch
+    # and RCCL set things up (allocations, the first collectives' connections, synchronisations) and the HIP runtime
+    # has been seen drawing from random() in such moments: the stream is parked until the build is done, so that the
+    # callers' next draws (bench.py: the query batches) are the same on every rank and in every run.
+    with _lib.park_random():
+        return _precomp_sharded_rest(lib, h, points, k, tries, dist, group, on, world, rank, via_cpu, want_dists, prec)
+
+
+def _precomp_sharded_rest(lib, h, points, k, tries, dist, group, on, world, rank, via_cpu, want_dists, prec):
+    import ctypes as C
+
+    from .api import Index
+    n, d = points.shape
     info = (C.c_size_t * 6)()
     lib.annhip_precomp_info(h, C.byref(info))
     Wn = int(info[1])

@@ -67,6 +67,9 @@ def parse():
                     help="also time one full batch in the opt-in fixed mode (recall_sample.fixed_mode.ms_per_step)")
     ap.add_argument("--no-strong-extra", action="store_true", help="N > 1: skip the fixed-batch (strong scaling) extra")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--tune-seconds", type=float, default=20.0,
+                    help="N > 1: wall-clock budget of the in-place schedule measurement before the warm-up (0 = keep the "
+                         "pinned schedule)")
     return ap.parse_args()
 
 
@@ -82,41 +85,78 @@ def describe(n, d, k, T, Q, dtype):
         "%sN=%d d=%d k=%d tries=%d Q=%d/step %s" % (tag + ": " if tag else "", n, d, k, T, Q, word)
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: start the N ranks as a FRESH child process -- nothing in this
+    process has touched the GPU (torch is not even imported yet), and the child is a child, never an exec -- relay its
+    output (the one JSON line included) and return its exit status."""
+    import socket
+    import subprocess
+    with socket.socket() as so:                 # a free rendezvous port on the loop-back interface
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # this pool's driver: dmabuf IPC only (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, bufsize=1)
+    for out_line in child.stdout:
+        sys.stdout.write(out_line)
+        sys.stdout.flush()
+    return child.wait()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     import numpy as np
     import torch
     import torch.distributed as dist
 
     import approximatenn_amd as A
+    from approximatenn_amd._lib import park_random, random_state_restore, random_state_snapshot
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
-        args.gpus = world
+        sys.exit("bench.py --gpus %d inside a job of %d ranks: start it as `python bench.py --gpus N` (it launches its own "
+                 "ranks) or under torch.distributed.run with --nproc-per-node equal to --gpus" % (args.gpus, world))
     shared_gpu = os.environ.get("ANN_BENCH_SHARED_GPU") == "1"  # rehearsal: all ranks on GPU 0, gloo collectives
     rehearse_rccl = os.environ.get("ANN_SHARD_FORCE_DIST") == "1" and "RANK" in os.environ  # 1 rank, real RCCL calls
     dev_index = 0 if shared_gpu else local_rank
     os.environ["ANN_HIP_DEVICE"] = str(dev_index)
+    if not shared_gpu and dev_index >= torch.cuda.device_count():
+        sys.exit("rank %d: no GPU %d on this node (%d visible)" % (rank, dev_index, torch.cuda.device_count()))
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     sharded = world > 1 or rehearse_rccl
+    rccl = None
     if sharded:
         if shared_gpu:
             dist.init_process_group(backend="gloo")
         else:  # "nccl" is RCCL on ROCm.  Its kernels run beside the other batch's gather, which would otherwise take
             # every freed wave slot first: give the communicator's stream the high priority the batches' streams have.
-            opts = None
-            try:
-                opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
-            except Exception:  # noqa: BLE001
-                pass
             import datetime
+            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
             # a rank that dies must not leave the others waiting for the default 10 minutes
             dist.init_process_group(backend="nccl", pg_options=opts, device_id=device, timeout=datetime.timedelta(seconds=240))
+        # who is really in this job: backend, communicator size and the physical devices behind the ranks
+        props = torch.cuda.get_device_properties(dev_index)
+        mine = {"rank": rank, "device": dev_index, "uuid": str(getattr(props, "uuid", "")), "name": props.name}
+        everyone = [None] * dist.get_world_size()
+        dist.all_gather_object(everyone, mine)
+        distinct = len({(e["device"], e["uuid"]) for e in everyone})
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001  (version query only; no collective involved)
+            ver = None
+        rccl = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rccl_version": ver,
+                "distinct_devices": distinct, "device_name": props.name, "high_priority_stream": not shared_gpu}
+        if dist.get_world_size() != args.gpus or (not shared_gpu and distinct != args.gpus):
+            sys.exit("rank %d: --gpus %d but the communicator has %d ranks on %d distinct devices"
+                     % (rank, args.gpus, dist.get_world_size(), distinct))
+    coll_dev = "cpu" if shared_gpu else device      # where the small control tensors of the collectives live
 
     n, d, k, T = args.n, args.d, args.k, args.tries
     tdt = torch.float32 if args.dtype == "f32" else torch.float64
@@ -125,41 +165,62 @@ def main():
     libc = ctypes.CDLL("libc.so.6")
     nbatches = args.warmup + args.steps
 
-    # ---- synthetic data + index (identical on every rank: same seed, deterministic build).  The libc random() stream
-    #      belongs to the workload (points -> precomp's rotations -> one draw per batch, time_results.c:94-103); the HIP
-    #      runtime draws from it too whenever it feels like it (observed at initialisation), so the stream is parked
-    #      while torch talks to the GPU -- the library does the same inside its own entry points.
-    class park_random:
-        def __enter__(self):
-            self.buf = ctypes.create_string_buffer(256)
-            libc.initstate.restype = ctypes.c_void_p
-            self.old = libc.initstate(ctypes.c_uint(1), self.buf, ctypes.c_size_t(256))
+    def bcast(t):
+        """rank 0's tensor to every rank (device tensor; staged through the host for the gloo rehearsal)."""
+        if not sharded or dist.get_world_size() == 1:
+            return t
+        if shared_gpu:
+            c = t.cpu()
+            dist.broadcast(c, src=0)
+            t.copy_(c)
+        else:
+            dist.broadcast(t, src=0)
+        return t
 
-        def __exit__(self, *exc):
-            libc.setstate.argtypes = [ctypes.c_void_p]
-            libc.setstate(self.old)
-
+    # ---- synthetic data + index.  The libc random() stream belongs to the workload (points -> precomp's rotations ->
+    #      one draw per batch, time_results.c:94-103).  RANK 0 ALONE generates the points and the batches and broadcasts
+    #      them (N ranks x 1.3 G Box-Muller values on the same host cores would take N times as long and N x 5 GB of
+    #      host memory); the stream's state after the points travels too, so that every rank's precomp draws the SAME
+    #      rotations from it (Q12).  The HIP runtime draws from random() whenever it feels like it (observed at
+    #      initialisation), so the stream is parked while torch talks to the GPU -- the library does the same inside.
     with park_random():
         torch.zeros(1, device=device)           # the runtime is fully up before the stream is seeded
         torch.cuda.synchronize()
     libc.srandom(args.seed)
     host_pts = None
     t0 = time.time()
+    gen = None
     if args.data == "randnorm":
-        host_pts = A.synth_randnorm(n * d, args.dtype, reset=True).reshape(n, d)   # time_results.c:94
+        if rank == 0:
+            host_pts = A.synth_randnorm(n * d, args.dtype, reset=True).reshape(n, d)   # time_results.c:94
         with park_random():
-            points = torch.from_numpy(host_pts).to(device)
+            points = torch.from_numpy(host_pts).to(device) if rank == 0 else torch.empty((n, d), dtype=tdt, device=device)
             torch.cuda.synchronize()
     else:
         with park_random():
             gen = torch.Generator(device=device)
             gen.manual_seed(args.seed)
-            points = torch.randn((n, d), device=device, dtype=tdt, generator=gen)
+            points = torch.randn((n, d), device=device, dtype=tdt, generator=gen) if rank == 0 else \
+                torch.empty((n, d), dtype=tdt, device=device)
             torch.cuda.synchronize()
+    if sharded:
+        snap = torch.zeros(256, dtype=torch.uint8)
+        if rank == 0:
+            state = random_state_snapshot()
+            snap[: len(state)] = torch.frombuffer(bytearray(state), dtype=torch.uint8)
+            snap[255] = len(state)
+        with park_random():
+            bcast(points)
+            snap = snap.to(coll_dev)
+            bcast(snap)
+            torch.cuda.synchronize()
+            snap = snap.cpu()
+        if rank != 0:
+            random_state_restore(bytes(snap[: int(snap[255])].tolist()))
     datagen_s = time.time() - t0
     t0 = time.time()
     if sharded:                                 # distance passes dealt to the ranks by bucket; three collectives
-        from approximatenn_amd.sharded import precomp_sharded
+        from approximatenn_amd.sharded import precomp_sharded, same_everywhere
         ix = precomp_sharded(points, k, T, dist=dist)
     else:
         ix = A.Index.precomp(points, k, T)      # draws its rotations from the same random() stream (Q12)
@@ -168,31 +229,49 @@ def main():
         precomp_s = time.time() - t0
         ix.set_stream(torch.cuda.current_stream().cuda_stream)
     if args.data == "randnorm":                 # one genRand per batch, in order (time_results.c:103)
-        host_batches = [A.synth_randnorm(Q * d, args.dtype).reshape(Q, d) for _ in range(nbatches)]
+        if rank == 0:
+            host_batches = [A.synth_randnorm(Q * d, args.dtype).reshape(Q, d) for _ in range(nbatches)]
         with park_random():
-            batches = [torch.from_numpy(b).to(device) for b in host_batches]
-        del host_batches
+            batches = [torch.from_numpy(host_batches[i]).to(device) if rank == 0 else torch.empty((Q, d), dtype=tdt, device=device)
+                       for i in range(nbatches)]
+        host_batches = None
     else:
         with park_random():
-            batches = [torch.randn((Q, d), device=device, dtype=tdt, generator=gen) for _ in range(nbatches)]
+            batches = [torch.randn((Q, d), device=device, dtype=tdt, generator=gen) if rank == 0 else
+                       torch.empty((Q, d), dtype=tdt, device=device) for _ in range(nbatches)]
+    if sharded:
+        with park_random():
+            for b in batches:
+                bcast(b)
+            torch.cuda.synchronize()
+            # Every rank must now hold the same index and the same batches: results depend on both, and ranks that
+            # disagree would answer wrongly or hang in mismatched collectives.  Checked, not assumed (exit status 3).
+            sums = same_everywhere(dist, [ix.checksum(), A.checksum(batches[0], args.dtype), A.checksum(batches[-1], args.dtype)],
+                                   "index / batch checksums", device=coll_dev)
+            rccl["index_checksum"] = "%016x" % sums[0]
 
     runner = None
+    pin = os.environ.get("ANN_SHARD_TUNE")
     if sharded:
         from approximatenn_amd.sharded import ShardedQuery
         lo, hi = (n * rank) // world, (n * (rank + 1)) // world
-        shard = points[lo:hi].clone()
-        ix.reshard(shard, lo, hi)
-        del points
-        torch.cuda.empty_cache()
+        with park_random():
+            shard = points[lo:hi].clone()
+            ix.reshard(shard, lo, hi)
+            del points
+            torch.cuda.empty_cache()
         runner = ShardedQuery(ix, dist, lanes=3)   # exchange agreed on by all ranks at start-up (all-to-all, else all-gather)
-        # up to three batches in flight: the exchanges of batch i run under the gathers of i+1, i+2.  How many lanes, the
-        # issue order and the CUs kept free for RCCL's kernels are measured here, before the warm-up (a few dozen untimed
-        # batches, same on every rank; no result bit depends on them).  ANN_SHARD_TUNE=depth,split,reserve,pieces pins them.
-        pin = os.environ.get("ANN_SHARD_TUNE")
-        if pin:
+        # Up to three batches in flight: the exchanges of batch i run under the gathers of i+1, i+2.  The job starts from
+        # ONE pinned schedule (ShardedQuery.PINNED); lanes, issue order and launches per gather are then measured in
+        # place within --tune-seconds of wall clock (untimed batches before the warm-up, every decision agreed on by
+        # all ranks; no result bit depends on it).  ANN_SHARD_TUNE=depth,split,reserve,pieces pins a schedule,
+        # ANN_SHARD_TUNE=off keeps the pinned default without measuring.
+        if pin and pin != "off":
             runner.configure(*[int(v) for v in pin.split(",")])
+        elif pin == "off" or args.tune_seconds <= 0:
+            runner.configure(*ShardedQuery.PINNED)
         else:
-            runner.autotune(batches[0])
+            runner.autotune(batches[0], budget_s=args.tune_seconds)
 
         def run_steps(ys):
             runner.pump(ys)
@@ -225,7 +304,7 @@ def main():
         barrier()
         el = time.perf_counter() - t0
         if sharded:
-            tt = torch.tensor([el], dtype=torch.float64, device="cpu" if shared_gpu else device)
+            tt = torch.tensor([el], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
         return el, submit
@@ -285,6 +364,7 @@ def main():
         line["config"]["stage_ms_per_step"] = {k_: round(v / args.steps, 4) for k_, v in stage_ms.items()}
     if runner is not None:
         line["config"]["exchange"] = runner.exchange
+        line["config"]["rccl"] = rccl
         line["config"]["queries_per_step_total"] = Q
         line["config"]["batches_in_flight"] = runner.depth
         line["config"]["schedule"] = runner.tuned or {"depth": runner.depth, "split": runner.split,
@@ -298,8 +378,8 @@ def main():
     if sharded and not args.no_strong_extra:
         Qs = args.q
         ys = [b[:Qs].contiguous() for b in batches]
-        if not pin:
-            runner.autotune(ys[0])          # a batch this small wants its own schedule
+        if not pin and args.tune_seconds > 0:
+            runner.autotune(ys[0], budget_s=args.tune_seconds / 2)   # a batch this small wants its own schedule
         run_steps(ys[:args.warmup])
         el_s, _ = timed(ys[args.warmup:])
         line["strong"] = {"queries_per_step_total": Qs, "value": round(Qs * args.steps / el_s, 1), "unit": "queries/s",

@@ -65,6 +65,10 @@ int annhip_save_read(const char *path, save_t *save);
  * editing, or set ANN_HIP_CACHE=strict (full content hash per call) / ANN_HIP_CACHE=off (upload per call).
  * annhip_cache_size() = resident indexes.  annhip_reload_env() re-reads the ANN_HIP_* switches (they are read once). */
 void annhip_cache_clear(void);
+/* Milliseconds one fingerprint of (save, points) takes on this host: strict != 0 = the full content hash that
+ * ANN_HIP_CACHE=strict pays on every query() call (spread over the host thread pool, ANN_HIP_HOST_THREADS, default
+ * min(cores, 16)), 0 = the sampled default.  Measurement only. */
+double annhip_fingerprint_ms(const save_t *save, const ftype *points, int strict);
 void annhip_cache_drop(const save_t *save);
 size_t annhip_cache_size(void);
 void annhip_reload_env(void);
@@ -202,6 +206,14 @@ void annhip_stage2_rows_list(annhip_index *ix, size_t ycnt, const ftype *y_dev, 
  * first k entries to out_id u32[.][k] / out_dist at row qidx_dev[i] (NULL = i). */
 void annhip_exact_select(annhip_index *ix, int stage, size_t nq, uint32_t *ids_dev, ftype *dist_dev,
                          const uint32_t *qidx_dev, uint32_t *out_id_dev, ftype *out_dist_dev);
+
+/* ---- content checksums (device memory in, 64-bit value out; synchronous) ------------------------------------------- */
+/* annhip_checksum_dev: checksum of nbytes of device memory (4-byte aligned), independent of the launch geometry.
+ * annhip_index_checksum: geometry, every bucket table, graph, means and projection rows of a resident index -- everything
+ * a query reads except the point rows.  A multi-GPU host all-reduces both with MIN and MAX at start-up: ranks that do not
+ * hold the same index and the same batch would return different answers (or hang in mismatched collectives). */
+unsigned long long annhip_checksum_dev(const void *dev_ptr, size_t nbytes, void *hip_stream);
+unsigned long long annhip_index_checksum(annhip_index *ix);
 
 /* ---- recall scoring (counterpart of /root/reference/test_correctness.c:169-262) --------------- */
 /* ranks_dev[q][j] (u64) = number of the n points strictly closer to query q than its j-th guessed neighbour, by one

@@ -69,6 +69,29 @@ def test_bench_multi_rank_branch_two_ranks_sharing_the_gpu():
     assert s["queries_per_step_total"] == 1000 and s["value"] > 0
 
 
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO torchrun around it -- how the driver starts every bench line: the script
+    starts its ranks as a fresh child process before anything touches the GPU, relays the one JSON line and the exit status."""
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["ANN_BENCH_SHARED_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--points", "200000", "--queries", "1000",
+           "--steps", "2", "--warmup", "1", "--no-strong-extra", "--tune-seconds", "5"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    r = d["config"]["rccl"]
+    assert r["world_size"] == 2 and r["backend"] == "gloo" and len(r["index_checksum"]) == 16
+    sch = d["config"]["schedule"]
+    assert sch["table"][0]["depth"] == 3 and sch["table"][0]["split"] is True      # the pinned schedule is measured first
+    # failing ranks give a non-zero exit status and no JSON line (here: an empty point set, which the library refuses)
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--points", "0"], capture_output=True,
+                         text=True, timeout=600, cwd=ROOT, env=env)
+    assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.strip().startswith("{")]
+
+
 def test_bench_multi_rank_fallback_exchange():
     """ANN_SHARD_EXCHANGE=allgather: the exchange every rank falls back to, together, when all_to_all_single is not
     available on the backend (decided collectively at start-up, sharded.py)."""
@@ -94,3 +117,5 @@ def test_bench_single_rank_over_rccl():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.strip().startswith("{")][0])
     assert d["n_gpus"] == 1 and d["config"]["exchange"] == "alltoall" and d["value"] > 0 and d["strong"]["value"] > 0
+    r = d["config"]["rccl"]         # proof of what the collectives ran on
+    assert r["backend"] == "nccl" and r["world_size"] == 1 and r["distinct_devices"] == 1 and r["rccl_version"]

@@ -98,6 +98,12 @@ def _worker_modes(rank, world, case, mode):
         assert len(res) == 4
         for ids, dd in res:
             assert np.array_equal(ids.numpy().astype(np.uint64), want_ids) and bits_equal(dd.numpy(), want_d)
+    elif mode == "autotune_budget":   # no budget left after the pinned candidate: every rank stops there, together
+        sq = ShardedQuery(eng, dist, lanes=3)
+        tuned = sq.autotune(yt, batches=2, budget_s=0.0)
+        assert len(tuned["table"]) == 1 and "stopped" in tuned
+        assert (tuned["depth"], tuned["split"], tuned["reserve_cus"], tuned["pieces"]) == ShardedQuery.PINNED
+        ids, dd = sq.pump([yt])[0]
     else:
         raise AssertionError(mode)
     assert np.array_equal(ids.numpy().astype(np.uint64), want_ids), "rank %d ids (%s)" % (rank, mode)
@@ -105,7 +111,8 @@ def _worker_modes(rank, world, case, mode):
 
 
 @pytest.mark.parametrize("world,case,mode", [(2, "tiny_appendixA_f32", "allgather"), (3, "few_candidates_f64", "allgather"),
-                                             (2, "odd_everything_f32", "exact"), (3, "tiny_appendixA_f32", "pipelined"), (2, "tiny_appendixA_f32", "autotune")])
+                                             (2, "odd_everything_f32", "exact"), (3, "tiny_appendixA_f32", "pipelined"), (2, "tiny_appendixA_f32", "autotune"),
+                                             (2, "tiny_appendixA_f32", "autotune_budget")])
 def test_sharded_query_modes(world, case, mode):
     port = 29500 + (os.getpid() + hash((case, mode))) % 2000
     mp.spawn(_worker, args=(world, port, case, mode), nprocs=world, join=True)
@@ -147,3 +154,53 @@ def test_single_rank_engine_matches_reference():
     eng = CpuShardEngine(g["save"], g["points"], 0, g["cfg"]["n"], "f32")
     ids, dd = ShardedQuery(eng, None).query(torch.from_numpy(g["y"]))
     assert np.array_equal(ids.numpy().astype(np.uint64), g["query_ids"]) and bits_equal(dd.numpy(), g["query_dists"])
+
+
+def _same_worker(rank, world, port, differ):
+    from approximatenn_amd.sharded import same_everywhere
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        vals = [0xFEDCBA9876543210, 7, (1 << 63) + 5]        # 64-bit patterns incl. the sign bit
+        assert same_everywhere(dist, vals, "test values") == vals
+        if differ:
+            vals[2] += rank                                   # rank 1 holds another checksum: EVERY rank must stop
+            with pytest.raises(SystemExit) as ei:
+                same_everywhere(dist, vals, "test values")
+            assert ei.value.code == 3
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_with_different_inputs_stop_together():
+    """bench.py's start-up check (same index, same batches on every rank): MIN/MAX all-reduce of checksums; a
+    difference ends every rank with exit status 3 instead of silently different answers or a hang."""
+    port = 29500 + (os.getpid() + 4242) % 2000
+    mp.spawn(_same_worker, args=(2, port, True), nprocs=2, join=True)
+
+
+def test_random_stream_hand_over_between_processes():
+    """bench.py generates the points on rank 0 only; the libc random() state after them is shipped to the other ranks
+    (approximatenn_amd._lib.random_state_snapshot / _restore) so that every rank's precomp draws the same rotations."""
+    import subprocess
+    import sys
+    from approximatenn_amd import _lib
+    O.srandom(2024)
+    for _ in range(1001):
+        O.libc_random()
+    snap = _lib.random_state_snapshot()
+    want = [O.libc_random() for _ in range(8)]
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from approximatenn_amd import _lib\nfrom oracle import oracle_py as O\n"
+            "O.srandom(1)\n_lib.random_state_restore(bytes.fromhex(%r))\n"
+            "print([O.libc_random() for _ in range(8)])" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), snap.hex()))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip() == str(want)
+    # parking is nestable and leaves the caller's stream where it was
+    _lib.random_state_restore(snap)
+    with _lib.park_random():
+        O.libc_random()
+        with _lib.park_random():
+            O.libc_random()
+    assert [O.libc_random() for _ in range(8)] == want
