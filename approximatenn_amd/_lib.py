@@ -126,6 +126,11 @@ def load(prec="f32"):
     lib.annhip_host_profile.argtypes = [C.c_int]
     lib.annhip_host_stats.restype = C.c_int
     lib.annhip_host_stats.argtypes = [C.POINTER(SaveT), C.POINTER(C.c_double * 8), C.c_int]
+    lib.annhip_host_shards.restype = C.c_int
+    lib.annhip_host_shards.argtypes = [C.POINTER(SaveT)]
+    lib.annhip_host_stats_shard.restype = C.c_int
+    lib.annhip_host_stats_shard.argtypes = [C.POINTER(SaveT), C.c_int, C.POINTER(C.c_double * 8), C.c_int]
+    lib.annhip_set_devices.argtypes = [C.c_int, C.c_int]
     lib.annhip_cache_drop.argtypes = [C.POINTER(SaveT)]
     lib.annhip_cache_size.restype = sz
     lib.annhip_cache_size.argtypes = []
@@ -152,7 +157,8 @@ EXPORTED = ["gpu_init", "gpu_cleanup", "register_cleanup", "query_gpu", "precomp
             "annhip_sh_final", "annhip_stage1_rows", "annhip_stage2_rows_list", "annhip_exact_select",
             "annhip_recall_ranks", "annhip_checksum_dev", "annhip_index_checksum", "annhip_profile", "annhip_stats", "annhip_stage_ms",
             "annhip_cache_clear", "annhip_fingerprint_ms", "annhip_cache_drop", "annhip_cache_size", "annhip_reload_env",
-            "annhip_synth_randnorm", "annhip_synth_reset", "annhip_host_profile", "annhip_host_stats"]
+            "annhip_synth_randnorm", "annhip_synth_reset", "annhip_host_profile", "annhip_host_stats",
+            "annhip_host_shards", "annhip_host_stats_shard", "annhip_set_devices"]
 DISPATCH_EXPORTED = ["precomp", "query", "free_save"]
 
 

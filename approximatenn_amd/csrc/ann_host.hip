@@ -195,7 +195,7 @@ struct PinBuf {  // grow-only pinned host memory
     if (bytes > cap) {
       if (p) HIPCHECK(hipHostFree(p));
       size_t want = bytes + bytes / 8 + 256;
-      HIPCHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
+      HIPCHECK(hipHostMalloc(&p, want, hipHostMallocPortable));
       cap = want;
     }
     return p;
@@ -1601,9 +1601,11 @@ struct annhip_precomp {
   hipStream_t s = 0;
 };
 
-extern "C" annhip_precomp *annhip_precomp_begin(size_t n, size_t k, size_t d, const ftype *points, int on_device, int tries,
-                                                size_t rots_before, size_t rot_len_before, size_t rots_after,
-                                                size_t rot_len_after, int rank, int world) {
+// reuse != NULL: the transforms another handle of the same build has drawn (a host that drives several shards from one
+// process draws once); otherwise they are drawn here from the caller's random() stream.
+static annhip_precomp *precomp_begin_impl(size_t n, size_t k, size_t d, const ftype *points, int on_device, int tries,
+                                          size_t rots_before, size_t rot_len_before, size_t rots_after,
+                                          size_t rot_len_after, int rank, int world, const std::vector<HostXform> *reuse) {
   if (n <= k || k < 1) die("need n > k >= 1");
   if (world < 1 || rank < 0 || rank >= world) die("annhip_precomp_begin: bad rank/world");
   // alg.c:347-357 (Q13: evaluated in ftype)
@@ -1621,12 +1623,16 @@ extern "C" annhip_precomp *annhip_precomp_begin(size_t n, size_t k, size_t d, co
   h->rots_before = rots_before, h->rot_len_before = rot_len_before, h->rots_after = rots_after, h->rot_len_after = rot_len_after;
   // Every transform is drawn up front, in the reference's order (alg.c:387-392, Q12), and BEFORE any HIP call:
   // these draws are the only use this path makes of the caller's random() stream.
-  h->hx.resize(T);
-  for (int t = 0; t < T; t++) {
-    h->hx[t].before = draw_givens(rots_before, rot_len_before, d);
-    h->hx[t].after = draw_givens(rots_after, rot_len_after, ds);
-    h->hx[t].perm_b = draw_perm(d, d_max);
-    h->hx[t].perm_ai = draw_perm(ds, d_max);
+  if (reuse) {
+    h->hx = *reuse;
+  } else {
+    h->hx.resize(T);
+    for (int t = 0; t < T; t++) {
+      h->hx[t].before = draw_givens(rots_before, rot_len_before, d);
+      h->hx[t].after = draw_givens(rots_after, rot_len_after, ds);
+      h->hx[t].perm_b = draw_perm(d, d_max);
+      h->hx[t].perm_ai = draw_perm(ds, d_max);
+    }
   }
   RandGuard keep_callers_stream;
   gpu_init();
@@ -1680,6 +1686,13 @@ extern "C" annhip_precomp *annhip_precomp_begin(size_t n, size_t k, size_t d, co
   HIPCHECK(hipMemset(ix->d_rows, 0, ANN_NCOUNTERS * sizeof(unsigned long long)));
   h->solo = dev_alloc<TryInfo>(1);
   return h;
+}
+
+extern "C" annhip_precomp *annhip_precomp_begin(size_t n, size_t k, size_t d, const ftype *points, int on_device, int tries,
+                                                size_t rots_before, size_t rot_len_before, size_t rots_after,
+                                                size_t rot_len_after, int rank, int world) {
+  return precomp_begin_impl(n, k, d, points, on_device, tries, rots_before, rot_len_before, rots_after, rot_len_after, rank,
+                            world, NULL);
 }
 
 // out[0..5] = d_short, merged row stride Wn (entries), tries whose distance pass runs, tries, n, k
@@ -1941,6 +1954,9 @@ extern "C" annhip_index *annhip_precomp_index(size_t n, size_t k, size_t d, cons
 // which_par IN PLACE between two query() calls on the same addresses must either call annhip_cache_drop(save) /
 // annhip_cache_clear(), or run with ANN_HIP_CACHE=strict (every call hashes the full content: exact, ~1 s per call
 // at cfg3) or ANN_HIP_CACHE=off (every call uploads, the reference's behaviour).
+static bool g_host_profile = false;
+#include "ann_multi_host.h"
+
 struct CacheEntry {
   const save_t *save;
   const ftype *points;
@@ -1948,9 +1964,14 @@ struct CacheEntry {
   size_t n, k, d;
   int T;
   u64 fp;
-  annhip_index *ix;
+  annhip_index *ix;      // the whole index on one device, or
+  annhip_multi *multi;   // ... its rows sharded over several (ANN_HIP_DEVICES / ANN_HIP_VIRTUAL_SHARDS)
 };
 static std::vector<CacheEntry> g_cache;
+static void entry_destroy(CacheEntry &e) {
+  if (e.multi) multi_destroy(e.multi);
+  else annhip_index_destroy(e.ix);
+}
 #define ANN_CACHE_SLOTS 4
 #define ANN_FP_SAMPLES 1024
 
@@ -2041,7 +2062,7 @@ extern "C" double annhip_fingerprint_ms(const save_t *save, const ftype *points,
 }
 
 static void cache_clear() {
-  for (auto &e : g_cache) annhip_index_destroy(e.ix);
+  for (auto &e : g_cache) entry_destroy(e);
   g_cache.clear();
 }
 extern "C" void annhip_cache_clear(void) { cache_clear(); }
@@ -2050,7 +2071,7 @@ extern "C" void annhip_cache_clear(void) { cache_clear(); }
 extern "C" void annhip_cache_drop(const save_t *save) {
   for (size_t i = 0; i < g_cache.size();) {
     if (g_cache[i].save == save) {
-      annhip_index_destroy(g_cache[i].ix);
+      entry_destroy(g_cache[i]);
       g_cache.erase(g_cache.begin() + i);
     } else {
       i++;
@@ -2062,19 +2083,53 @@ extern "C" size_t annhip_cache_size(void) { return g_cache.size(); }
 // Measurement through the host-pointer ABI (tests/harness/time_results): the resident indexes behind
 // query_gpu() record their stage-1 launches like annhip_profile() does; annhip_host_stats() = annhip_stats() of the
 // index resident for `save` (0, or -1 if none), with out[6] = P1 and out[7] = L1 added.
-static bool g_host_profile = false;
 extern "C" void annhip_host_profile(int on) {
   g_host_profile = on != 0;
-  for (auto &e : g_cache) e.ix->profile = g_host_profile;
+  for (auto &e : g_cache) {
+    if (e.ix) e.ix->profile = g_host_profile;
+    if (e.multi)
+      for (auto &S : e.multi->sh) S.ix->profile = g_host_profile;
+  }
 }
-extern "C" int annhip_host_stats(const save_t *save, double out[8], int reset) {
+// shard < 0: the whole resident index (a sharded one: launches and milliseconds of the slowest shard, rows summed)
+static int host_stats(const save_t *save, int shard, double out[8], int reset) {
   for (auto &e : g_cache)
     if (e.save == save) {
-      annhip_stats(e.ix, out, reset);
-      out[6] = (double)e.ix->P1, out[7] = (double)e.ix->L1;
+      if (e.ix) {
+        if (shard > 0) return -1;
+        annhip_stats(e.ix, out, reset);
+        out[6] = (double)e.ix->P1, out[7] = (double)e.ix->L1;
+        return 0;
+      }
+      annhip_multi *M = e.multi;
+      if (shard >= M->G) return -1;
+      double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int g = 0; g < M->G; g++) {
+        if (shard >= 0 && g != shard) continue;
+        DevScope ds(M->sh[g].dev);
+        double v[8];
+        annhip_stats(M->sh[g].ix, v, reset);
+        acc[0] = std::max(acc[0], v[0]), acc[1] = std::max(acc[1], v[1]);
+        acc[2] += v[2], acc[3] += v[3];
+        acc[5] = std::max(acc[5], v[5]);
+      }
+      acc[4] = M->exact_queries;
+      if (reset) M->exact_queries = 0;
+      memcpy(out, acc, sizeof acc);
+      out[6] = (double)M->sh[0].ix->P1, out[7] = (double)M->sh[0].ix->L1;
       return 0;
     }
   return -1;
+}
+extern "C" int annhip_host_stats(const save_t *save, double out[8], int reset) { return host_stats(save, -1, out, reset); }
+extern "C" int annhip_host_stats_shard(const save_t *save, int shard, double out[8], int reset) {
+  return shard < 0 ? -1 : host_stats(save, shard, out, reset);
+}
+// number of devices / virtual shards the index resident for `save` is spread over (1 = one device; 0 = none resident)
+extern "C" int annhip_host_shards(const save_t *save) {
+  for (auto &e : g_cache)
+    if (e.save == save) return e.multi ? e.multi->G : 1;
+  return 0;
 }
 
 static bool same_key(const CacheEntry &e, const save_t *sv, const ftype *points) {
@@ -2082,39 +2137,47 @@ static bool same_key(const CacheEntry &e, const save_t *sv, const ftype *points)
 }
 
 // insert, replacing any entry with the same (save, points) key; oldest entry evicted when full
-static void cache_put(const save_t *sv, const ftype *points, u64 fp, annhip_index *ix) {
+static void cache_put(const save_t *sv, const ftype *points, u64 fp, annhip_index *ix, annhip_multi *multi = NULL) {
   for (size_t i = 0; i < g_cache.size();) {
     if (same_key(g_cache[i], sv, points)) {
-      annhip_index_destroy(g_cache[i].ix);
+      entry_destroy(g_cache[i]);
       g_cache.erase(g_cache.begin() + i);
     } else {
       i++;
     }
   }
   if (g_cache.size() >= ANN_CACHE_SLOTS) {
-    annhip_index_destroy(g_cache.front().ix);
+    entry_destroy(g_cache.front());
     g_cache.erase(g_cache.begin());
   }
-  ix->profile = g_host_profile;
-  g_cache.push_back(CacheEntry{sv, points, sv->graph, sv->n, sv->k, sv->d_long, sv->tries, fp, ix});
+  if (ix) ix->profile = g_host_profile;
+  g_cache.push_back(CacheEntry{sv, points, sv->graph, sv->n, sv->k, sv->d_long, sv->tries, fp, ix, multi});
 }
 
-static annhip_index *cache_get(const save_t *sv, const ftype *points) {
+static bool multi_matches(const CacheEntry &e, const MultiCfg &mc) {
+  return mc.G > 0 ? (e.multi && e.multi->G == mc.G && e.multi->virt == mc.virt) : e.multi == NULL;
+}
+
+static CacheEntry cache_get(const save_t *sv, const ftype *points) {
   const u64 fp = fingerprint(sv, points);
+  const MultiCfg mc = multi_cfg();
   for (size_t i = 0; i < g_cache.size();) {
     CacheEntry &e = g_cache[i];
     if (!same_key(e, sv, points)) {
       i++;
       continue;
     }
-    if (e.fp == fp && e.graph == sv->graph && e.n == sv->n && e.k == sv->k && e.d == sv->d_long && e.T == sv->tries)
-      return e.ix;
-    annhip_index_destroy(e.ix);  // same addresses, different content: stale
+    if (e.fp == fp && e.graph == sv->graph && e.n == sv->n && e.k == sv->k && e.d == sv->d_long && e.T == sv->tries &&
+        multi_matches(e, mc))
+      return e;
+    entry_destroy(e);  // same addresses, different content (or another device set): stale
     g_cache.erase(g_cache.begin() + i);
   }
-  annhip_index *ix = annhip_index_create(sv, points, 0, 0, sv->n);
-  cache_put(sv, points, fp, ix);
-  return ix;
+  if (mc.G > 0)
+    cache_put(sv, points, fp, NULL, multi_create(mc, sv, points));
+  else
+    cache_put(sv, points, fp, annhip_index_create(sv, points, 0, 0, sv->n));
+  return g_cache.back();
 }
 
 // ----------------------------------------------------------------------------- drop-in symbols
@@ -2123,10 +2186,17 @@ extern "C" size_t *query_gpu(const save_t *save, const ftype *points, size_t ycn
   RandGuard keep_callers_stream;
   gpu_init();
   const bool resident = env().cache_mode != 2;  // ANN_HIP_CACHE=off: upload per call, as the reference does
-  annhip_index *ix = resident ? cache_get(save, points) : annhip_index_create(save, points, 0, 0, save->n);
+  const MultiCfg mc = multi_cfg();
   const size_t k = save->k, d = save->d_long;
   size_t *result = (size_t *)malloc(sizeof(size_t) * (ycnt * k ? ycnt * k : 1));
   if (dists_o) *dists_o = (ftype *)malloc(sizeof(ftype) * (ycnt * k ? ycnt * k : 1));
+  if (mc.G > 0) {  // rows sharded over several devices (or virtual shards): the owner protocol, ann_multi_host.h
+    annhip_multi *M = resident ? cache_get(save, points).multi : multi_create(mc, save, points);
+    if (ycnt) multi_query(M, ycnt, y, y == points, result, dists_o ? *dists_o : NULL);
+    if (!resident) multi_destroy(M);
+    return result;
+  }
+  annhip_index *ix = resident ? cache_get(save, points).ix : annhip_index_create(save, points, 0, 0, save->n);
   if (!ycnt) {
     if (!resident) annhip_index_destroy(ix);
     return result;
@@ -2166,6 +2236,23 @@ extern "C" size_t *query_gpu(const save_t *save, const ftype *points, size_t ycn
 extern "C" size_t *precomp_gpu(size_t n, size_t k, size_t d, const ftype *points, int tries,
                                size_t rots_before, size_t rot_len_before, size_t rots_after,
                                size_t rot_len_after, save_t *save, ftype **dists_o) {
+  if (multi_cfg().G > 0) {  // the build spread over the devices; each keeps its row slice resident afterwards
+    size_t *graph = NULL;
+    annhip_multi *M = multi_precomp(multi_cfg(), n, k, d, points, tries, rots_before, rot_len_before, rots_after,
+                                    rot_len_after, &graph, dists_o);
+    RandGuard keep_callers_stream;
+    if (save) {
+      {
+        DevScope ds(M->sh[0].dev);
+        annhip_index_export(M->sh[0].ix, save);
+      }
+      if (env().cache_mode != 2) cache_put(save, points, fingerprint(save, points), NULL, M);
+      else multi_destroy(M);
+    } else {
+      multi_destroy(M);
+    }
+    return graph;
+  }
   // (annhip_precomp_index draws from the caller's random() stream first, then parks it)
   annhip_index *ix = annhip_precomp_index(n, k, d, points, 0, tries, rots_before, rot_len_before, rots_after,
                                           rot_len_after, NULL);

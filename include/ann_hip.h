@@ -73,6 +73,17 @@ void annhip_cache_drop(const save_t *save);
 size_t annhip_cache_size(void);
 void annhip_reload_env(void);
 
+/* ---- point rows sharded over several devices behind query_gpu()/precomp_gpu() (the reference is
+ * single-device, gpu_comp.c:60-75) -------------------------------------------------------------------------------- */
+/* ndev > 1: from now on precomp_gpu() builds across devices 0..ndev-1 of this process and query_gpu() keeps one resident
+ * index per device -- rows [g*n/ndev,(g+1)*n/ndev) on device g, tables and graph replicated -- and answers by the owner
+ * protocol (the annhip_sh_* sequence below; exchanges over RCCL: ncclCommInitAll, one group per exchange; librccl.so is
+ * loaded on first use).  virtual_shards > 0 instead: that many shards on the CURRENT device with loop-back exchanges
+ * (same host code and kernels; for single-GPU boxes and tests).  (0, 0) = one device, the default.  Results are
+ * bit-identical in every mode.  The environment does the same without a code change: ANN_HIP_DEVICES=G,
+ * ANN_HIP_VIRTUAL_SHARDS=G; a call to this function overrides it. */
+void annhip_set_devices(int ndev, int virtual_shards);
+
 /* ---- precomp on the device (alg.c:342-434) ----------------------------------------------------- */
 /* Builds the index from ALL n rows on this device and keeps it resident.  Consumes libc random() in the
  * reference's order.  graph_dists_dev (device, ftype[n*k]) may be NULL. */
@@ -247,6 +258,11 @@ void annhip_stage_ms(annhip_index *ix, double out[6]);
  * plus out[6] = P1, out[7] = L1 (returns 0, or -1 when no index is resident for it). */
 void annhip_host_profile(int on);
 int annhip_host_stats(const save_t *save, double out[8], int reset);
+/* A sharded resident index (annhip_set_devices): annhip_host_shards() = the devices / virtual shards the index resident
+ * for `save` is spread over (1 = one device, 0 = none resident); annhip_host_stats_shard() = annhip_host_stats() of one
+ * shard (annhip_host_stats() itself then reports the slowest shard's launches / milliseconds and the rows summed). */
+int annhip_host_shards(const save_t *save);
+int annhip_host_stats_shard(const save_t *save, int shard, double out[8], int reset);
 
 #ifdef __cplusplus
 }

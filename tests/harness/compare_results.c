@@ -9,6 +9,7 @@
 #include <limits.h>
 
 #include "harness_common.h"
+#include "ann_hip.h"
 
 #ifdef USE_FLOAT
 #define ifabs abs
@@ -54,10 +55,11 @@ static double cdiff_save(const save_t *a, const save_t *b) { /* compare_results.
 }
 
 int main(int argc, char **argv) {
-  opts_t o = parse_opts(argc, argv, "n:k:d:t:o:y:b:s:a:r:S:hvz", 3);
+  opts_t o = parse_opts(argc, argv, "n:k:d:t:o:y:b:s:a:r:S:G:V:hvz", 3);
   if (o.use_y && !o.ycnt) o.ycnt = 50;
   srandom(o.seed);
   gpu_init();
+  if (o.devices > 1 || o.vshards > 0) annhip_set_devices(o.devices, o.vshards);
   ftype *points = malloc(sizeof(ftype) * o.n * o.d);
   double score = 0;
   size_t dist_bad = 0, dist_bits = 0, id_bad = 0;

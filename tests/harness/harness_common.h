@@ -23,7 +23,7 @@ extern void oracle_gen_rand(size_t count, ftype *out);
 typedef struct {
   size_t n, k, d, tries, reps, ycnt, rb, rlenb, ra, rlena, cpu_queries;
   unsigned seed;
-  int verbose, use_y, use_cpu, save_test, lanes;
+  int verbose, use_y, use_cpu, save_test, lanes, devices, vshards, fp_cost;
 } opts_t;
 
 static void usage(const char *prog) {
@@ -34,12 +34,15 @@ static void usage(const char *prog) {
           "\t-y query count  -z (compare: -y 50; time: save the index)  -c CPU column only  -v verbose\n"
           "\t-S seed for srandom() (12345; the reference seeds with time(NULL))\n"
           "\t-P lanes (time_results only): also time the pipelined host API (annhip_stream_*) with that many lanes\n"
+          "\t-G devices: shard the point rows over that many GPUs of this process (annhip_set_devices; RCCL exchanges)\n"
+          "\t-V shards: the same with that many VIRTUAL shards on one GPU (loop-back exchanges)\n"
+          "\t-F (time_results only): print what one residency-cache fingerprint costs (sampled default and strict)\n"
           "\t-C queries (time_results only): size of the batch the CPU column is timed on (default: -y for the oracle,\n"
           "\t   128 for the reference's query_cpu)\n", prog);
 }
 
 static opts_t parse_opts(int argc, char **argv, const char *letters, size_t default_reps) {
-  opts_t o = {1000, 10, 80, 10, default_reps, 0, 6, 1, 1, 1, 0, 12345u, 0, 0, 0, 0, 0};
+  opts_t o = {1000, 10, 80, 10, default_reps, 0, 6, 1, 1, 1, 0, 12345u, 0, 0, 0, 0, 0, 0, 0, 0};
   int c;
   opterr = 0;
   while ((c = getopt(argc, argv, letters)) != -1) switch (c) {
@@ -59,6 +62,9 @@ static opts_t parse_opts(int argc, char **argv, const char *letters, size_t defa
       case 'c': o.use_cpu = 1; break;
       case 'P': o.lanes = (int)strtol(optarg, NULL, 0); break;
       case 'C': o.cpu_queries = strtoul(optarg, NULL, 0); break;
+      case 'G': o.devices = (int)strtol(optarg, NULL, 0); break;
+      case 'V': o.vshards = (int)strtol(optarg, NULL, 0); break;
+      case 'F': o.fp_cost = 1; break;
       default: usage(argv[0]); exit(c == 'h' ? 0 : 2);
     }
   return o;

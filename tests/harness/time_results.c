@@ -29,9 +29,10 @@ static query_cpu_fn load_reference(const char *argv0) {
 }
 
 int main(int argc, char **argv) {
-  opts_t o = parse_opts(argc, argv, "n:k:d:t:o:y:b:s:a:r:S:P:C:hzvc", 10);
+  opts_t o = parse_opts(argc, argv, "n:k:d:t:o:y:b:s:a:r:S:P:C:G:V:Fhzvc", 10);
   srandom(o.seed);
   if (!o.use_cpu) gpu_init();
+  if (o.devices > 1 || o.vshards > 0) annhip_set_devices(o.devices, o.vshards);
   ftype *points = malloc(sizeof(ftype) * o.n * o.d), *dists;
   annhip_synth_reset();
   annhip_synth_randnorm(o.n * o.d, points);                 /* genRand, time_results.c:94 */
@@ -81,7 +82,20 @@ int main(int argc, char **argv) {
                100 * gbs / HBM_PEAK, HBM_PEAK);
         printf("whole call (host buffers in and out, PCIe included): %.1f GB/s algorithmic = %.1f %% of the HBM peak\n",
                gb / avg, 100 * gb / avg / HBM_PEAK);
+        /* rows sharded over several devices (-G / -V): every device's own gather against its own HBM */
+        const int shards = annhip_host_shards(&save);
+        for (int g = 0; shards > 1 && g < shards; g++) {
+          double sg[8];
+          if (annhip_host_stats_shard(&save, g, sg, 0) != 0 || sg[0] <= 0 || sg[5] <= 0) continue;
+          const double v1g = sg[2] / sg[5], msg = sg[1] / sg[0];
+          const double bg = (v1g * o.d * s + sg[6] * 4 + o.d * s + o.tries * 4.0 + (o.k + 1) * (s + 4)) * o.ycnt / 1e9;
+          printf("  shard %d of %d: stage-1 kernel %.4f ms, %.1f rows gathered per query, %.3f GB  => %.1f GB/s = %.1f %% of its HBM peak\n",
+                 g, shards, msg, v1g, bg, bg / (msg * 1e-3), 100 * bg / (msg * 1e-3) / HBM_PEAK);
+        }
       }
+      if (o.fp_cost)
+        printf("residency-cache fingerprint per query() call: sampled (default) %.3f ms, strict (ANN_HIP_CACHE=strict, full "
+               "content) %.1f ms\n", annhip_fingerprint_ms(&save, points, 0), annhip_fingerprint_ms(&save, points, 1));
     }
     if (!o.use_cpu && o.lanes > 0) {
       /* the same kind of batches through the pipelined host API: uploads, kernels and downloads overlap */
