@@ -74,6 +74,8 @@ struct EnvCfg {
   size_t lds_row_max = 150 * 1024, exact_bytes = (size_t)1 << 30;
   size_t exact_rows = 0;  // ANN_HIP_EXACT_ROWS: rows of the device-driven exact workspace (0 = auto)
   int cache_mode = 0;  // ANN_HIP_CACHE: 0 sampled fingerprint (default), 1 strict (full content hash), 2 off
+  int regnet = 1;       // ANN_HIP_REGNET: 0 = the exact path's literal network always in its LDS form, 1 = register form
+                        // for the few rows of a batch's exact path (default), 2 = register form whenever the shape fits (tests)
   size_t bk_group = 0;  // ANN_HIP_BK_GROUP: cap on the members per pass of precomp's bucket kernel (0 = what fits the LDS)
 };
 static EnvCfg g_env;
@@ -102,6 +104,7 @@ static void load_env() {
   c.exact_bytes = env_size("ANN_HIP_EXACT_BYTES", (size_t)1 << 30);
   c.exact_rows = env_size("ANN_HIP_EXACT_ROWS", 0);
   c.bk_group = env_size("ANN_HIP_BK_GROUP", 0);
+  c.regnet = env_int("ANN_HIP_REGNET", 1);
   const char *cm = getenv("ANN_HIP_CACHE");
   c.cache_mode = !cm ? 0 : !strcmp(cm, "strict") ? 1 : !strcmp(cm, "off") ? 2 : 0;
   g_env = c;
@@ -803,6 +806,17 @@ static void launch_exact_select(u32 L, u32 len, u32 in_stride, int k, size_t nq,
   if (block < 64) block = 64;
   const size_t smem = (size_t)len * (sizeof(FT) + sizeof(u32));
   const unsigned grid = live_rows ? (unsigned)std::min<size_t>(nq, 512) : (unsigned)nq;
+  // a handful of long rows (the flagged queries of a batch): the register form of the same network, ~8x less latency
+  const u32 Pn = 1u << lk;
+  if (env().regnet && L >= 16 && Pn >= 1024 && Pn <= 16384 && (u32)k <= Pn && len >= std::min(L, Pn + 1) &&
+      (live_rows || nq <= 64 || env().regnet == 2) && Pn / ANN_RN_E <= max_block) {
+    const size_t sm = (size_t)Pn * (sizeof(FT) + sizeof(u32)) + 64;
+    allow_lds(exact_select_reg_kernel, sm);
+    hipLaunchKernelGGL(exact_select_reg_kernel, dim3(grid), dim3(Pn / ANN_RN_E), sm, s, L, len, in_stride, k, ids, dist, qidx,
+                       xbase, out_i, out_d, ostride, ooff, live_rows, (u32)nq, out64, live_off);
+    HIPCHECK(hipGetLastError());
+    return;
+  }
   if (smem <= env().lds_row_max) {  // the whole row in LDS (a CU has 160 KB); longer rows sort in place in HBM
     allow_lds(exact_select_kernel<true>, smem);
     hipLaunchKernelGGL(exact_select_kernel<true>, dim3(grid), dim3(block), smem, s, L, len, in_stride, k,
@@ -1986,6 +2000,18 @@ struct FpHash {  // four independent multiply lanes over 64-bit words: a few GB/
   void bytes(const void *p, size_t nbytes) {
     const unsigned char *b = (const unsigned char *)p;
     size_t i = 0;
+    if (nbytes >= 4096) {
+      // bulk: eight independent multiply-add lanes over 64-byte lines (x = x*K + word, K odd: any changed word changes
+      // its lane), enough instruction-level parallelism to hash at memory speed; folded into the four lanes at the end
+      u64 x[8] = {1, 2, 3, 4, 5, 6, 7, 8};
+      for (; i + 64 <= nbytes; i += 64) {
+        u64 v[8];
+        memcpy(v, b + i, 64);
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = x[j] * 0x9E3779B97F4A7C15ull + v[j];
+      }
+      for (int j = 0; j < 8; j++) word(x[j]);
+    }
     for (; i + 8 <= nbytes; i += 8) {
       u64 v;
       memcpy(&v, b + i, 8);
@@ -2158,6 +2184,32 @@ static bool multi_matches(const CacheEntry &e, const MultiCfg &mc) {
   return mc.G > 0 ? (e.multi && e.multi->G == mc.G && e.multi->virt == mc.virt) : e.multi == NULL;
 }
 
+// the entry resident for these addresses whose geometry is the save_t's (no look at the content), or -1
+static int cache_find(const save_t *sv, const ftype *points, const MultiCfg &mc) {
+  for (size_t i = 0; i < g_cache.size(); i++) {
+    const CacheEntry &e = g_cache[i];
+    if (!same_key(e, sv, points) || e.graph != sv->graph || e.n != sv->n || e.k != sv->k || e.d != sv->d_long ||
+        e.T != sv->tries || !multi_matches(e, mc))
+      continue;
+    const annhip_index *ix = e.ix ? e.ix : e.multi->sh[0].ix;
+    bool same = ix->ds == sv->d_short;
+    for (int t = 0; same && t < sv->tries; t++) same = ix->h_tries[t].pm == sv->par_maxes[t];
+    if (same) return (int)i;
+  }
+  return -1;
+}
+
+static void annhip_cache_drop_key(const save_t *sv, const ftype *points) {
+  for (size_t i = 0; i < g_cache.size();) {
+    if (same_key(g_cache[i], sv, points)) {
+      entry_destroy(g_cache[i]);
+      g_cache.erase(g_cache.begin() + i);
+    } else {
+      i++;
+    }
+  }
+}
+
 static CacheEntry cache_get(const save_t *sv, const ftype *points) {
   const u64 fp = fingerprint(sv, points);
   const MultiCfg mc = multi_cfg();
@@ -2181,55 +2233,147 @@ static CacheEntry cache_get(const save_t *sv, const ftype *points) {
 }
 
 // ----------------------------------------------------------------------------- drop-in symbols
+// query_gpu on one device, in two halves.  begin: the batch arrives in pageable host memory (ann.h:61-62); ONE job of the
+// host pool copies it into a pinned bounce buffer in pieces of >= 256 KB, in order, and this thread sends each piece --
+// and launches the hash of its queries (the codes are per query; only stage 1 needs all of them, Q2) -- as soon as the
+// piece is there; then the rest of the step and the copies of the results into a pinned buffer, all asynchronous.
+// end: wait, hand the results over in malloc'd memory.  Between the two the host is idle: query_gpu verifies the
+// residency fingerprint there.
+static double g_tmark[8];
+static int g_tmark_on = -1;
+static inline void tmark(int i) {
+  if (g_tmark_on < 0) g_tmark_on = getenv("ANN_HIP_HOST_TIMING") != NULL;
+  if (!g_tmark_on) return;
+  struct timespec t;
+  clock_gettime(CLOCK_MONOTONIC, &t);
+  g_tmark[i] = t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
+}
+// 16 bytes per thread and step from pinned HOST memory (the GPU reads it across PCIe) to device memory: a kernel, not a
+// DMA command -- each switch between the copy engine and the compute queue costs ~25 us of stream time (measured: the
+// batch sent as 20 hipMemcpyAsync pieces with a hash launch after each took 0.65 ms longer than the kernels themselves)
+typedef unsigned int copy_vec4 __attribute__((ext_vector_type(4)));
+__global__ void copy_in_kernel(size_t n16, const copy_vec4 *__restrict__ src, copy_vec4 *__restrict__ dst, size_t tail, size_t nbytes) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = __builtin_nontemporal_load(src + i);
+  if (blockIdx.x == 0 && threadIdx.x < tail)
+    reinterpret_cast<unsigned char *>(dst)[nbytes - tail + threadIdx.x] = reinterpret_cast<const unsigned char *>(src)[nbytes - tail + threadIdx.x];
+}
+
+static void *pinned_dev_ptr(void *host) {
+  void *dp = NULL;
+  HIPCHECK(hipHostGetDevicePointer(&dp, host, 0));
+  return dp;
+}
+
+static void query_single_begin(annhip_index *ix, size_t ycnt, const ftype *y, int alias, bool want_d) {
+  tmark(0);
+  const size_t k = ix->k, d = ix->d;
+  FT *y_dev = (FT *)ix->io_y.need(sizeof(FT) * ycnt * d);
+  char *y_pin = (char *)ix->io_y_pin.need(sizeof(FT) * ycnt * d);
+  const char *y_pin_dev = (const char *)pinned_dev_ptr(y_pin);
+  hipStream_t s = ix->stream;
+  const QParams P = make_params(ix);
+  const size_t row = sizeof(FT) * d, hashed = codes_needed(ix, ycnt);
+  static const int io_pieces = env_int("ANN_HIP_IO_PIECES", 2);
+  const size_t pieces = std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, io_pieces), ycnt * row >> 20));
+  const size_t per = (ycnt + pieces - 1) / pieces;
+  u32 *codes = (u32 *)ix->ws.codes.need(sizeof(u32) * ycnt * P.T);
+  std::vector<std::atomic<int>> copied(pieces);
+  for (auto &c : copied) c.store(0, std::memory_order_relaxed);
+  // every piece is itself copied by several pool threads: items = pieces x lanes, taken in order
+  const size_t lanes = std::max<size_t>(1, std::min<size_t>(HostPool::get().threads(), per * row >> 16));
+  const std::function<void(size_t)> copy_part = [&](size_t it) {
+    const size_t i = it / lanes, l = it % lanes;
+    const size_t q0 = i * per, nq = q0 < ycnt ? std::min(per, ycnt - q0) : 0;
+    const size_t bytes = nq * row, a = (bytes * l / lanes) & ~(size_t)63, b = l + 1 == lanes ? bytes : (bytes * (l + 1) / lanes) & ~(size_t)63;
+    if (b > a) memcpy(y_pin + q0 * row + a, (const char *)y + q0 * row + a, b - a);
+    copied[i].fetch_add(1, std::memory_order_release);
+  };
+  HostPool::get().begin(pieces * lanes, copy_part);
+  for (size_t i = 0; i < pieces; i++) {
+    const size_t q0 = i * per, nq = q0 < ycnt ? std::min(per, ycnt - q0) : 0;
+    while ((size_t)copied[i].load(std::memory_order_acquire) < lanes) {
+    }
+    if (!nq) continue;
+    const size_t bytes = nq * row;  // rows are multiples of 4 bytes at least; the tail handles what is not 16
+    copy_in_kernel<<<grid_for(bytes / 16 ? bytes / 16 : 1, 256, 512), 256, 0, s>>>(
+        bytes / 16, reinterpret_cast<const copy_vec4 *>(y_pin_dev + q0 * row), reinterpret_cast<copy_vec4 *>((char *)y_dev + q0 * row),
+        bytes % 16, bytes);
+    if (q0 < hashed) launch_codes(P, std::min(nq, hashed - q0), y_dev + q0 * d, codes + q0 * P.T, s);
+  }
+  HIPCHECK(hipGetLastError());
+  HostPool::get().end();
+  tmark(1);
+  // the final kernels write ids and distances straight into pinned host memory: no copy command at the end either
+  const size_t ib = sizeof(size_t) * ycnt * k, db = sizeof(FT) * ycnt * k;
+  char *out_pin = (char *)ix->io_out_pin.need(ib + db);
+  char *out_dev = (char *)pinned_dev_ptr(out_pin);
+  query_impl(ix, ix->ws, s, ycnt, reinterpret_cast<const ftype *>(y_dev), alias, 0, reinterpret_cast<size_t *>(out_dev),
+             reinterpret_cast<ftype *>(out_dev + ib), true);
+  (void)want_d;
+  tmark(2);
+}
+
+static void query_single_end(annhip_index *ix, size_t ycnt, size_t *result, ftype *dists) {
+  const size_t ib = sizeof(size_t) * ycnt * ix->k, db = dists ? sizeof(FT) * ycnt * ix->k : 0;
+  tmark(3);
+  HIPCHECK(hipStreamSynchronize(ix->stream));
+  tmark(4);
+  const char *out_pin = (const char *)ix->io_out_pin.p;
+  HostPool::get().copy(result, out_pin, ib);
+  if (db) HostPool::get().copy(dists, out_pin + ib, db);
+  tmark(5);
+  if (g_tmark_on > 0)
+    fprintf(stderr, "query_gpu host timeline (ms): batch in + hashes enqueued %.3f, step enqueued %.3f, fingerprint %.3f, "
+            "wait %.3f, results out %.3f\n", g_tmark[1] - g_tmark[0], g_tmark[2] - g_tmark[1], g_tmark[3] - g_tmark[2],
+            g_tmark[4] - g_tmark[3], g_tmark[5] - g_tmark[4]);
+}
+
 extern "C" size_t *query_gpu(const save_t *save, const ftype *points, size_t ycnt, const ftype *y,
                              ftype **dists_o) {
   RandGuard keep_callers_stream;
   gpu_init();
   const bool resident = env().cache_mode != 2;  // ANN_HIP_CACHE=off: upload per call, as the reference does
   const MultiCfg mc = multi_cfg();
-  const size_t k = save->k, d = save->d_long;
+  const size_t k = save->k;
   size_t *result = (size_t *)malloc(sizeof(size_t) * (ycnt * k ? ycnt * k : 1));
   if (dists_o) *dists_o = (ftype *)malloc(sizeof(ftype) * (ycnt * k ? ycnt * k : 1));
-  if (mc.G > 0) {  // rows sharded over several devices (or virtual shards): the owner protocol, ann_multi_host.h
-    annhip_multi *M = resident ? cache_get(save, points).multi : multi_create(mc, save, points);
-    if (ycnt) multi_query(M, ycnt, y, y == points, result, dists_o ? *dists_o : NULL);
-    if (!resident) multi_destroy(M);
-    return result;
+  ftype *dists = dists_o ? *dists_o : NULL;
+  const int alias = y == points;
+  // An index resident for these addresses with this geometry is used OPTIMISTICALLY: the step is enqueued first, the
+  // content fingerprint (sampled by default, everything under ANN_HIP_CACHE=strict) is computed while the GPU works,
+  // and only a mismatch -- the caller edited the index or the points in place -- costs anything: the results are
+  // discarded, the index is uploaded again and the step repeated.  (Running a step on a stale resident index is
+  // harmless: it is self-contained in device memory and its geometry equals the new one's.)
+  for (int attempt = 0;; attempt++) {
+    const int hit = resident && attempt == 0 ? cache_find(save, points, mc) : -1;
+    CacheEntry e;
+    if (hit >= 0) e = g_cache[hit];
+    else if (resident) e = cache_get(save, points);  // uploads (and replaces a stale entry)
+    else {
+      e = CacheEntry{save, points, save->graph, save->n, save->k, save->d_long, save->tries, 0, NULL, NULL};
+      if (mc.G > 0) e.multi = multi_create(mc, save, points);
+      else e.ix = annhip_index_create(save, points, 0, 0, save->n);
+    }
+    bool stale = false;
+    const std::function<void()> verify = [&] {
+      if (hit >= 0) stale = fingerprint(save, points) != e.fp;
+    };
+    if (ycnt) {
+      if (e.multi) {  // rows sharded over several devices (or virtual shards): the owner protocol, ann_multi_host.h
+        multi_query(e.multi, ycnt, y, alias, result, dists, &verify);
+      } else {
+        query_single_begin(e.ix, ycnt, y, alias, dists != NULL);
+        verify();
+        query_single_end(e.ix, ycnt, result, dists);
+      }
+    } else {
+      verify();
+    }
+    if (!resident) entry_destroy(e);
+    if (!stale) break;
+    annhip_cache_drop_key(save, points);  // the next attempt uploads the current content
   }
-  annhip_index *ix = resident ? cache_get(save, points).ix : annhip_index_create(save, points, 0, 0, save->n);
-  if (!ycnt) {
-    if (!resident) annhip_index_destroy(ix);
-    return result;
-  }
-  // The batch arrives in pageable host memory (ann.h:61-62).  It is copied into a pinned bounce buffer by the host
-  // pool and sent in pieces: while piece i+1 is being copied on the host, piece i crosses PCIe and its queries are
-  // hashed (the codes are per query; only stage 1 needs all of them, Q2).  Results come back through one pinned buffer.
-  FT *y_dev = (FT *)ix->io_y.need(sizeof(FT) * ycnt * d);
-  size_t *ids_dev = (size_t *)ix->io_ids.need(sizeof(size_t) * ycnt * k);
-  FT *dist_dev = (FT *)ix->io_dist.need(sizeof(FT) * ycnt * k);
-  char *y_pin = (char *)ix->io_y_pin.need(sizeof(FT) * ycnt * d);
-  hipStream_t s = ix->stream;
-  const QParams P = make_params(ix);
-  const size_t row = sizeof(FT) * d, hashed = codes_needed(ix, ycnt);
-  const size_t pieces = std::max<size_t>(1, std::min<size_t>(8, ycnt * row >> 20));  // >= 1 MB each
-  const size_t per = (ycnt + pieces - 1) / pieces;
-  u32 *codes = (u32 *)ix->ws.codes.need(sizeof(u32) * ycnt * P.T);
-  for (size_t q0 = 0; q0 < ycnt; q0 += per) {
-    const size_t nq = std::min(per, ycnt - q0);
-    HostPool::get().copy(y_pin + q0 * row, (const char *)y + q0 * row, nq * row);
-    HIPCHECK(hipMemcpyAsync((char *)y_dev + q0 * row, y_pin + q0 * row, nq * row, hipMemcpyHostToDevice, s));
-    if (q0 < hashed) launch_codes(P, std::min(nq, hashed - q0), y_dev + q0 * d, codes + q0 * P.T, s);
-  }
-  query_impl(ix, ix->ws, s, ycnt, reinterpret_cast<const ftype *>(y_dev), y == points, 0, ids_dev,
-             reinterpret_cast<ftype *>(dist_dev), true);
-  const size_t ib = sizeof(size_t) * ycnt * k, db = dists_o ? sizeof(FT) * ycnt * k : 0;
-  char *out_pin = (char *)ix->io_out_pin.need(ib + db);
-  HIPCHECK(hipMemcpyAsync(out_pin, ids_dev, ib, hipMemcpyDeviceToHost, s));
-  if (db) HIPCHECK(hipMemcpyAsync(out_pin + ib, dist_dev, db, hipMemcpyDeviceToHost, s));
-  HIPCHECK(hipStreamSynchronize(s));
-  HostPool::get().copy(result, out_pin, ib);
-  if (db) HostPool::get().copy(*dists_o, out_pin + ib, db);
-  if (!resident) annhip_index_destroy(ix);
   return result;
 }
 

@@ -48,6 +48,38 @@ class HostPool {
     fn_ = NULL;
   }
 
+  // The same, asynchronously: begin() hands the items to the WORKERS only and returns at once; the caller goes on (e.g.
+  // watches per-item completion flags the items set, and feeds finished pieces to the GPU) and calls end() to wait for
+  // the job.  With a pool of one thread begin() runs the items inline.
+  void begin(size_t items, const std::function<void(size_t)> &fn) {
+    job_mu_.lock();
+    async_inline_ = false;
+    if (!items) return;
+    if (nthr_ <= 1) {
+      for (size_t i = 0; i < items; i++) fn(i);
+      return;
+    }
+    start_workers();
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      fn_ = &fn, items_ = items;
+      next_.store(0);
+      pending_ = (unsigned)workers_.size();
+      generation_++;
+    }
+    async_inline_ = true;
+    cv_.notify_all();
+  }
+  void end() {
+    if (async_inline_) {
+      work();  // help with whatever is left
+      std::unique_lock<std::mutex> lk(mu_);
+      done_cv_.wait(lk, [&] { return pending_ == 0; });
+      fn_ = NULL;
+    }
+    job_mu_.unlock();
+  }
+
   // memcpy spread over the pool in pieces of at least `grain` bytes
   void copy(void *dst, const void *src, size_t bytes, size_t grain = (size_t)1 << 18) {
     if (bytes <= 2 * grain || nthr_ <= 1) {
@@ -95,6 +127,7 @@ class HostPool {
     }
   }
   unsigned nthr_ = 1;
+  bool async_inline_ = false;
   std::vector<std::thread> workers_;
   std::mutex mu_, job_mu_;
   std::condition_variable cv_, done_cv_;

@@ -287,7 +287,10 @@ static annhip_multi *multi_create(const MultiCfg &cfg, const save_t *save, const
 // ----------------------------------------------------------------------------- query: one batch, synchronous
 #define MULTI_FCAP 32  // flagged queries the device-driven exact path takes per step (sharded.py: fcap)
 
-static void multi_query(annhip_multi *M, size_t Q, const ftype *y_host, int alias, size_t *ids_out, ftype *dists_out) {
+// overlap: called once everything of the step is enqueued and before the host waits for it (query_gpu verifies the
+// residency fingerprint there)
+static void multi_query(annhip_multi *M, size_t Q, const ftype *y_host, int alias, size_t *ids_out, ftype *dists_out,
+                        const std::function<void()> *overlap = NULL) {
   const int G = M->G;
   const size_t k = M->k, d = M->d, qs = (Q + G - 1) / G, Qp = qs * G;
   annhip_index *ix0 = M->sh[0].ix;
@@ -387,6 +390,7 @@ static void multi_query(annhip_multi *M, size_t Q, const ftype *y_host, int alia
       HIPCHECK(hipMemcpyAsync(head + 1, (u32 *)S.flist.p + 1, sizeof(u32), hipMemcpyDeviceToHost, S.s));
     }
   }
+  if (overlap) (*overlap)();
   for (int g = 0; g < G; g++) {
     if (M->virt && g > 0) break;
     DevScope ds(M->sh[g].dev);

@@ -484,6 +484,154 @@ size_t *oracle_precomp(size_t n, size_t k, size_t d, const ft *points, int tries
   return result;
 }
 
+/* ------------------------------------- precomp, sampled (large configs) */
+
+/* The index-building half of oracle_precomp for a SAMPLE of the rows: column
+ * means (alg.c:360-369), the T transforms drawn from random() in the
+ * reference's order (Q12; the same number of draws as a full precomp),
+ * bases (save_vecs, alg.c:189-217) and the hash codes of the sampled rows
+ * (run_initial, alg.c:154-183).  Lets a test check a GPU-built save_t at
+ * BASELINE sizes in seconds: means and bases in full, and -- by looking the
+ * sampled points up in which_par[t][code] -- the bucket tables by sample.
+ * means_out ft[d], bases_out ft[T*ds*d], codes_out size_t[nrows*T]
+ * (codes_out[i*T+t] = code of point rows[i] in try t).  Returns d_short. */
+size_t oracle_precomp_tables_sample(size_t n, size_t k, size_t d, const ft *points,
+                                    int tries, size_t rots_before, size_t rot_len_before,
+                                    size_t rots_after, size_t rot_len_after,
+                                    size_t nrows, const size_t *rows, ft *means_out,
+                                    ft *bases_out, size_t *codes_out) {
+  size_t ds = (size_t)ceil(log2((ft)n / k)); /* Q13 */
+  size_t d_max = 1;
+  while (d_max < d)
+    d_max <<= 1;
+  if (ds > d_max)
+    ds = d_max;
+  size_t T = (size_t)tries, half = n / 2;
+  ft *acc = malloc(sizeof(ft) * (half ? half : 1) * d);
+  for (size_t x = 0; x < half; x++)
+    for (size_t y = 0; y < d; y++) {
+      ft g = ((n & 1) && x == 0) ? points[(n - 1) * d + y] : 0;
+      acc[x * d + y] = points[x * d + y] + points[(x + half) * d + y] + g;
+    }
+  for (size_t m = n >> 1; m >> 1; m >>= 1)
+    for (size_t x = 0; x < m / 2; x++)
+      for (size_t y = 0; y < d; y++) {
+        ft g = (x == 0 && (m & 1)) ? acc[(m - 1) * d + y] : 0;
+        acc[x * d + y] += acc[(x + m / 2) * d + y] + g;
+      }
+  for (size_t y = 0; y < d; y++) {
+    acc[y] /= n;
+    means_out[y] = acc[y];
+  }
+  free(acc);
+  transform_t *tf = malloc(sizeof(transform_t) * T);
+  for (size_t t = 0; t < T; t++)
+    tf[t] = draw_transform(rot_len_before, rots_before, rot_len_after, rots_after, ds, d, d_max);
+  ft *work = malloc(sizeof(ft) * d), *wide = malloc(sizeof(ft) * d_max);
+  ft *low = malloc(sizeof(ft) * (ds ? ds : 1)), *cen = malloc(sizeof(ft) * d);
+  for (size_t t = 0; t < T; t++) {
+    for (size_t i = 0; i < nrows; i++) {
+      for (size_t y = 0; y < d; y++)
+        cen[y] = points[rows[i] * d + y] - means_out[y];
+      forward_row(&tf[t], ds, d, d_max, cen, work, wide, low);
+      codes_out[i * T + t] = sign_code(ds, low);
+    }
+    for (size_t r = 0; r < ds; r++)
+      inverse_row(&tf[t], ds, d, d_max, r, wide, bases_out + (t * ds + r) * d);
+    free_transform(&tf[t]);
+  }
+  free(tf), free(work), free(wide), free(low), free(cen);
+  return ds;
+}
+
+/* Merged, sorted stage-1 row of point x (second_half per try, alg.c:245-290,
+ * then det_results' first topk_stage over the k*T merged entries,
+ * alg.c:308-312) from a COMPLETE index: which_par gives the candidates, the
+ * point's own code in try t is the bucket it sits in (code_of[t][x]). */
+static void merged_row_of(const oracle_save_t *save, const ft *points, size_t x,
+                          size_t *const *code_of, size_t *ids, ft *key, ft *scratch) {
+  size_t n = save->n, k = save->k, d = save->d_long, ds = save->d_short;
+  size_t T = (size_t)save->tries, W = k * T;
+  for (size_t t = 0; t < T; t++) {
+    size_t pm = save->par_maxes[t], L = (ds + 1) * pm, code = code_of[t][x];
+    size_t *row_ids = malloc(sizeof(size_t) * at_least_1(L));
+    ft *row_key = malloc(sizeof(ft) * at_least_1(L));
+    for (size_t y = 0; y <= ds; y++) {
+      size_t b = code ^ (y ? (size_t)1 << (y - 1) : 0);
+      for (size_t z = 0; z < pm; z++) {
+        size_t id = save->which_par[t][b * pm + z];
+        int ok = id < n && id != x;
+        row_ids[y * pm + z] = id;
+        row_key[y * pm + z] = sq_dist(d, points + x * d, points + (ok ? id : 0) * d, ok, scratch);
+      }
+    }
+    oracle_topk_stage(L, row_ids, row_key);
+    memcpy(ids + t * k, row_ids, sizeof(size_t) * k);
+    memcpy(key + t * k, row_key, sizeof(ft) * k);
+    free(row_ids), free(row_key);
+  }
+  oracle_topk_stage(W, ids, key);
+}
+
+/* Graph rows (and their squared distances) of the points rows[0..nrows) as
+ * precomp returns them (alg.c:419-433), computed from a complete save_t: the
+ * merged rows of each sampled point and of the k points its refinement reads
+ * (Q16), then refine_row.  out_ids size_t[nrows*k], out_dists ft[nrows*k].
+ * Returns 0, or -1 if a point is missing from a bucket table. */
+int oracle_precomp_graph_rows(const oracle_save_t *save, const ft *points, size_t nrows,
+                              const size_t *rows, size_t *out_ids, ft *out_dists) {
+  size_t n = save->n, k = save->k, d = save->d_long, ds = save->d_short;
+  size_t T = (size_t)save->tries, W = k * T, L2 = k * (k + 1), nb = (size_t)1 << ds;
+  size_t **code_of = malloc(sizeof(size_t *) * T);
+  int bad = 0;
+  for (size_t t = 0; t < T; t++) {
+    code_of[t] = malloc(sizeof(size_t) * n);
+    for (size_t x = 0; x < n; x++)
+      code_of[t][x] = (size_t)-1;
+    size_t pm = save->par_maxes[t];
+    for (size_t b = 0; b < nb; b++)
+      for (size_t z = 0; z < pm; z++) {
+        size_t id = save->which_par[t][b * pm + z];
+        if (id < n)
+          code_of[t][id] = b;
+      }
+    for (size_t x = 0; x < n; x++)
+      bad |= code_of[t][x] == (size_t)-1;
+  }
+  ft *scratch = malloc(sizeof(ft) * d);
+  size_t *mx_i = malloc(sizeof(size_t) * W), *par_i = malloc(sizeof(size_t) * W);
+  ft *mx_k = malloc(sizeof(ft) * W), *par_k = malloc(sizeof(ft) * W);
+  size_t *row_ids = malloc(sizeof(size_t) * L2);
+  ft *row_key = malloc(sizeof(ft) * L2);
+  for (size_t i = 0; i < nrows && !bad; i++) {
+    size_t x = rows[i];
+    merged_row_of(save, points, x, code_of, mx_i, mx_k, scratch);
+    for (size_t z = 0; z < k; z++) {
+      row_ids[z] = mx_i[z];
+      row_key[z] = mx_k[z];
+    }
+    for (size_t y = 0; y < k; y++) { /* supercharge, compute.cl:252-263 (Q7), graph == merged rows (Q16) */
+      size_t parent = mx_i[y];
+      merged_row_of(save, points, parent < n ? parent : 0, code_of, par_i, par_k, scratch);
+      for (size_t z = 0; z < k; z++)
+        row_ids[(y + 1) * k + z] = parent < n ? par_i[z] : (par_i[z] | n);
+    }
+    for (size_t j = k; j < L2; j++) {
+      size_t id = row_ids[j];
+      int ok = id < n && id != x;
+      row_key[j] = sq_dist(d, points + x * d, points + (ok ? id : 0) * d, ok, scratch);
+    }
+    oracle_topk_stage(L2, row_ids, row_key);
+    memcpy(out_ids + i * k, row_ids, sizeof(size_t) * k);
+    memcpy(out_dists + i * k, row_key, sizeof(ft) * k);
+  }
+  for (size_t t = 0; t < T; t++)
+    free(code_of[t]);
+  free(code_of), free(scratch), free(mx_i), free(mx_k), free(par_i), free(par_k);
+  free(row_ids), free(row_key);
+  return bad ? -1 : 0;
+}
+
 /* -------------------------------------------------------------- query */
 
 /* Hash codes of a query batch in the reference's WRITE layout

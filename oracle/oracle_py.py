@@ -189,6 +189,45 @@ class CpuBackend:
                 _libc.free(save.row_means), _libc.free(save.bases)
         return ids, dists, arrays
 
+    def precomp_tables_sample(self, points, k, tries, rows, rb=6, rlb=1, ra=1, rla=1):
+        """oracle_precomp_tables_sample: means, bases and the hash codes of the sampled rows, drawing the transforms
+        from libc random() exactly as a full precomp does.  Returns (d_short, means[d], bases[T,ds,d], codes[nrows,T])."""
+        assert self.kind == "oracle"
+        points = np.ascontiguousarray(points, dtype=self.ft)
+        n, d = points.shape
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        ds = int(np.ceil(np.log2(self.ft(n) / self.ft(k))))
+        d_max = 1
+        while d_max < d:
+            d_max *= 2
+        ds = min(ds, d_max)
+        means = np.empty(d, dtype=self.ft)
+        bases = np.empty((tries, ds, d), dtype=self.ft)
+        codes = np.empty((len(rows), tries), dtype=np.uint64)
+        f = self.lib.oracle_precomp_tables_sample
+        f.restype = C.c_size_t
+        f.argtypes = [C.c_size_t] * 3 + [C.c_void_p, C.c_int] + [C.c_size_t] * 5 + [C.c_void_p] * 4
+        got = f(n, k, d, points.ctypes.data, tries, rb, rlb, ra, rla, len(rows), rows.ctypes.data, means.ctypes.data,
+                bases.ctypes.data, codes.ctypes.data)
+        assert got == ds, (got, ds)
+        return ds, means, bases, codes
+
+    def precomp_graph_rows(self, save_arrays, points, rows):
+        """oracle_precomp_graph_rows: the graph rows precomp returns for the sampled points, from a complete save_t."""
+        assert self.kind == "oracle"
+        hs = save_arrays if isinstance(save_arrays, HostSave) else HostSave(save_arrays, self.prec)
+        points = np.ascontiguousarray(points, dtype=self.ft)
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        k = int(hs.c.k)
+        ids = np.empty((len(rows), k), dtype=np.uint64)
+        dd = np.empty((len(rows), k), dtype=self.ft)
+        f = self.lib.oracle_precomp_graph_rows
+        f.restype = C.c_int
+        f.argtypes = [C.POINTER(SaveT), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+        if f(C.byref(hs.c), points.ctypes.data, len(rows), rows.ctypes.data, ids.ctypes.data, dd.ctypes.data) != 0:
+            raise ValueError("a point is missing from a bucket table")
+        return ids, dd
+
     def query(self, save_arrays, points, y, alias=False, stats=False):
         """alias=True reproduces the y==points pointer-equality self exclusion (Q3)."""
         hs = save_arrays if isinstance(save_arrays, HostSave) else HostSave(save_arrays, self.prec)

@@ -97,3 +97,29 @@ def test_query_scramble_q2():
     assert 0 < self_found < len(g["copy_ids"])
     # aliased y == points excludes self entirely (Q3)
     assert not np.any(g["alias_ids"] == np.arange(len(g["alias_ids"]))[:, None])
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_sampled_precomp_checks_agree_with_the_full_oracle(prec):
+    """oracle_precomp_tables_sample / oracle_precomp_graph_rows (what tests/test_gpu_configs.py checks a GPU-built index of
+    BASELINE size with) against the full oracle_precomp -- itself pinned to the reference: same means, bases, draws from
+    random(), bucket membership of the sampled points, graph rows and distances."""
+    orc = O.CpuBackend(prec, "oracle")
+    for (n, d, k, T) in [(3000, 64, 10, 10), (1500, 80, 7, 4), (700, 33, 3, 5)]:
+        O.srandom(5)
+        orc.rand_norm_reset()
+        pts = orc.gen_rand(n * d).reshape(n, d)
+        O.srandom(77)
+        ids, dd, save = orc.precomp(pts, k, T)
+        after = O.libc_random()
+        rows = np.array([0, 1, n // 2, n - 1, 17, n // 3], dtype=np.uint64)
+        O.srandom(77)
+        ds, means, bases, codes = orc.precomp_tables_sample(pts, k, T, rows)
+        assert O.libc_random() == after
+        assert ds == save["d_short"] and bits_equal(means, save["row_means"]) and bits_equal(bases, save["bases"])
+        for i, x in enumerate(rows):
+            for t in range(T):
+                assert x in save["which_par"][t][int(codes[i, t])]
+        gi, gd = orc.precomp_graph_rows(save, pts, rows)
+        sel = rows.astype(np.int64)
+        assert np.array_equal(gi, ids[sel]) and bits_equal(gd, dd[sel])
