@@ -64,6 +64,7 @@ def load(prec="f32"):
     lib.annhip_index_info.argtypes = [vp, C.POINTER(sz * 12)]
     lib.annhip_index_set_stream.argtypes = [vp, vp]
     lib.annhip_index_set_gather_pieces.argtypes = [vp, C.c_int]
+    lib.annhip_index_set_gather_slots.argtypes = [vp, C.c_int]
     lib.annhip_index_set_fixed.argtypes = [vp, C.c_int]
     lib.annhip_index_export.argtypes = [vp, C.POINTER(SaveT)]
     lib.annhip_index_reshard.argtypes = [vp, vp, sz, sz]
@@ -90,6 +91,8 @@ def load(prec="f32"):
     lib.annhip_workspace_destroy.argtypes = [vp]
     lib.annhip_query_on.restype = C.c_long
     lib.annhip_query_on.argtypes = [vp, vp, vp, sz, vp, C.c_int, C.c_int, vp, vp]
+    lib.annhip_query_slice.restype = C.c_long
+    lib.annhip_query_slice.argtypes = [vp, vp, vp, sz, sz, sz, vp, u32p, C.c_int, vp, vp]
     lib.annhip_stream_open.restype = vp
     lib.annhip_stream_open.argtypes = [vp, sz, C.c_int]
     lib.annhip_stream_submit.restype = C.c_long
@@ -150,9 +153,9 @@ def load(prec="f32"):
 
 # every symbol include/*.h declares for the backend library (checked by tests/test_abi.py)
 EXPORTED = ["gpu_init", "gpu_cleanup", "register_cleanup", "query_gpu", "precomp_gpu", "annhip_precision",
-            "annhip_index_create", "annhip_index_destroy", "annhip_index_info", "annhip_index_set_stream", "annhip_index_set_gather_pieces", "annhip_index_set_fixed",
+            "annhip_index_create", "annhip_index_destroy", "annhip_index_info", "annhip_index_set_stream", "annhip_index_set_gather_pieces", "annhip_index_set_gather_slots", "annhip_index_set_fixed",
             "annhip_index_export", "annhip_index_reshard", "annhip_save_write", "annhip_save_read", "annhip_precomp_index", "annhip_precomp_begin", "annhip_precomp_info", "annhip_precomp_init_merged", "annhip_precomp_hash",
-            "annhip_precomp_try", "annhip_precomp_merge", "annhip_precomp_graph", "annhip_precomp_finish", "annhip_query", "annhip_workspace_create", "annhip_workspace_destroy", "annhip_query_on", "annhip_stream_open", "annhip_stream_submit", "annhip_stream_collect", "annhip_stream_close",
+            "annhip_precomp_try", "annhip_precomp_merge", "annhip_precomp_graph", "annhip_precomp_finish", "annhip_query", "annhip_workspace_create", "annhip_workspace_destroy", "annhip_query_on", "annhip_query_slice", "annhip_stream_open", "annhip_stream_submit", "annhip_stream_collect", "annhip_stream_close",
             "annhip_key_bytes", "annhip_stream_create_reserving", "annhip_stream_destroy", "annhip_sh_codes", "annhip_sh_stage1", "annhip_sh_merge_finalize", "annhip_sh_exact1_begin", "annhip_sh_exact1_end", "annhip_sh_stage2",
             "annhip_sh_final", "annhip_stage1_rows", "annhip_stage2_rows_list", "annhip_exact_select",
             "annhip_recall_ranks", "annhip_checksum_dev", "annhip_index_checksum", "annhip_profile", "annhip_stats", "annhip_stage_ms",

@@ -68,6 +68,7 @@ struct EnvCfg {
   bool exact = false, slot_scan = false, point_precomp = false, all_tries = false;
   int fuse = -1;      // ANN_HIP_FUSE: -1 unset, 0 never, 1 whenever possible
   int s1_waves = 0;   // ANN_HIP_S1_WAVES: 0 unset
+  int s1_slots = 0;   // ANN_HIP_S1_SLOTS: annhip_query's stage 1 as a persistent grid holding that many waves per SIMD (0 = off)
   int tail = -1;      // ANN_HIP_TAIL: 0 = stage 2 as separate rows / network / widen kernels (the classic path, A/B and tests)
   int s2_threads = 64;  // ANN_HIP_S2_THREADS: workgroup size of the fused stage-2 kernel (64, or 128; cfg3: 64-66 vs 67-68 us)
   int segx = -1;      // ANN_HIP_SEGX: -1 unset (auto: shards of <= 30 % of the rows), 0 never, 1 whenever the shard qualifies
@@ -97,6 +98,7 @@ static void load_env() {
   c.fuse = env_int("ANN_HIP_FUSE", -1);
   c.s1_waves = env_int("ANN_HIP_S1_WAVES", 0);
   if (c.s1_waves < 1 || c.s1_waves > 4) c.s1_waves = 0;
+  c.s1_slots = std::max(0, std::min(8, env_int("ANN_HIP_S1_SLOTS", 0)));
   c.segx = env_int("ANN_HIP_SEGX", -1);
   c.tail = env_int("ANN_HIP_TAIL", -1);
   c.s2_threads = env_int("ANN_HIP_S2_THREADS", 64) == 128 ? 128 : 64;
@@ -216,6 +218,17 @@ static T *dev_alloc(size_t count) {
   return (T *)p;
 }
 
+static int device_cus() {  // compute units of the current device (cached per device)
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (!cus[dev]) {
+    hipDeviceProp_t prop;
+    cus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  return cus[dev];
+}
+
 static unsigned grid_for(size_t work, unsigned block, unsigned cap = 1u << 20) {
   size_t g = (work + block - 1) / block;
   if (g < 1) g = 1;
@@ -272,6 +285,7 @@ struct annhip_index {
   double s1_ms = 0;
   double s1_launches = 0, queries = 0;
   int gather_pieces = 1;  // annhip_sh_stage1 in this many launches (annhip_index_set_gather_pieces)
+  int gather_slots = 0;   // annhip_sh_stage1 as a persistent grid holding this many waves per SIMD (0 = one workgroup per query)
   int fixed = 0;          // annhip_index_set_fixed: opt-in non-parity query mode (Q1/Q2 undone)
 };
 
@@ -285,7 +299,7 @@ static QParams make_params(const annhip_index *ix) {
   P.n = (u32)ix->n, P.lo = (u32)ix->lo, P.hi = (u32)ix->hi;
   P.d = (int)ix->d, P.k = (int)ix->k, P.T = ix->T, P.ds = (int)ix->ds;
   P.L1 = ix->L1, P.P1 = ix->P1, P.Lc1 = ix->Lc1, P.L2 = ix->L2, P.Lc2 = ix->Lc2;
-  P.q0 = 0;
+  P.q0 = 0, P.qn = 0;
   P.fixed = ix->fixed ? 1u : 0u;
   if (ix->fixed) P.P1 = P.Lc1 = P.L1;  // every slot of the candidate row takes part
   return P;
@@ -371,6 +385,9 @@ static void check_limits(size_t n, size_t k, size_t d, size_t ds, int T) {
 
 extern "C" void annhip_index_set_stream(annhip_index *ix, void *s) { ix->stream = (hipStream_t)s; }
 extern "C" void annhip_index_set_gather_pieces(annhip_index *ix, int pieces) { ix->gather_pieces = pieces < 1 ? 1 : pieces; }
+extern "C" void annhip_index_set_gather_slots(annhip_index *ix, int waves_per_simd) {
+  ix->gather_slots = waves_per_simd < 0 ? 0 : waves_per_simd > 8 ? 8 : waves_per_simd;
+}
 extern "C" void annhip_index_set_fixed(annhip_index *ix, int fixed) { ix->fixed = fixed ? 1 : 0; }
 
 extern "C" annhip_index *annhip_index_create(const save_t *save, const ftype *points, int on_device,
@@ -663,7 +680,10 @@ __global__ void sum_u32_kernel(size_t count, const u32 *__restrict__ v, unsigned
 static void launch_stage1(annhip_index *ix, const QParams &P, size_t Q, const FT *y, int alias,
                           const u32 *codes, FT *cand_d, u32 *cand_i, u32 *nvt, u32 *nvo, hipStream_t s,
                           const std::vector<TryInfo> &h_tries, int use_seg, FusedTail F = FusedTail{0, 0, NULL, NULL, NULL, NULL, NULL},
-                          Key *cand_key = NULL, int pieces = 1) {
+                          Key *cand_key = NULL, int pieces = 1, int slots = 0, size_t qstride = 0) {
+  // qstride: stride of the try-major code array the kernel reads as codes[try * qstride + x] (0 = Q; a host that answers
+  // a SLICE of a larger batch passes the whole batch's size and a code pointer offset to the slice, annhip_query_slice)
+  const int kq = (int)(qstride ? qstride : Q);
   if (!Q) return;
   const int K1 = P.k + 1, W = stage1_waves(P.P1, (double)(P.hi - P.lo) / (double)P.n), cap = stage1_cap(W, K1);
   const size_t smem = stage1_lds_bytes(P, W, K1, cap, F.enabled ? F.len2 : 0);
@@ -671,6 +691,13 @@ static void launch_stage1(annhip_index *ix, const QParams &P, size_t Q, const FT
   for (int t = 0; t < P.T; t++)
     for (int yy = 0; yy <= P.ds; yy++)
       if (h_tries[t].off + (u32)yy * h_tries[t].pm < P.P1) runs_used++;
+  // slots > 0: a PERSISTENT grid that holds at most `slots` waves on every SIMD and walks the queries itself.  The
+  // one-workgroup-per-query launch refills every freed wave slot at once, and a workgroup of several waves from another
+  // stream -- the small kernels of the other in-flight batches, RCCL's collectives -- is then not placed until the
+  // gather drains (measured: an RCCL kernel sat for 1.09 of a 1.25 ms gather, and the GPU then idled 0.45 ms per step
+  // while the chain behind it ran).  With one slot per SIMD left alone they start at once.
+  unsigned max_grid = 0xFFFFFFFFu;
+  if (slots > 0) max_grid = std::max(1u, (unsigned)device_cus() * 4u * (unsigned)slots / (unsigned)W);
   EventPair ev;
   const bool prof = ix && ix->profile;
   if (prof) {
@@ -691,9 +718,9 @@ static void launch_stage1(annhip_index *ix, const QParams &P, size_t Q, const FT
     const size_t np = (size_t)std::max(1, std::min(pieces, 64)), per = (Q + np - 1) / np;                    \
     for (size_t a = 0; a < Q; a += per) {                                                                    \
       QParams Pp = P;                                                                                        \
-      Pp.q0 = (u32)a;                                                                                        \
-      hipLaunchKernelGGL((stage1_select_kernel<DD, SG, FU>), dim3((unsigned)std::min(per, Q - a)), dim3(64 * W), smem, s, \
-                         Pp, (int)Q, y, alias, codes, K1, cap, runs_used, cand_d, cand_i, nvt, nvo, F, cand_key); \
+      Pp.q0 = (u32)a, Pp.qn = (u32)std::min(per, Q - a);                                                     \
+      hipLaunchKernelGGL((stage1_select_kernel<DD, SG, FU>), dim3(std::min<unsigned>(Pp.qn, max_grid)), dim3(64 * W), smem, s, \
+                         Pp, kq, y, alias, codes, K1, cap, runs_used, cand_d, cand_i, nvt, nvo, F, cand_key); \
     }                                                                                                        \
   } while (0)
 #define CALL(DD)                                 \
@@ -768,8 +795,10 @@ static size_t rows_lds_bytes(const QParams &P, u32 chunk) {
 template <int MODE>
 static void launch_rows(const QParams &P, size_t Q, const FT *y, int alias, const u32 *codes, const u32 *qidx,
                         u32 xbase, size_t nq, u32 len, const u32 *top_i, const FT *top_d, u32 *ids, FT *dist,
-                        unsigned long long *rows_done, hipStream_t s, const u32 *live_rows = NULL, u32 live_off = 0) {
+                        unsigned long long *rows_done, hipStream_t s, const u32 *live_rows = NULL, u32 live_off = 0,
+                        size_t qstride = 0) {
   if (!nq) return;
+  const int kq = (int)(qstride ? qstride : Q);  // stride of the code array (see launch_stage1)
   // long rows (exact path, a handful of rows) are split over up to 8 workgroups; short rows get one
   const unsigned split = len >= 1024 ? 8 : 1;
   u32 chunk = len < ANN_RD_CHUNK ? ((len + 63u) & ~63u) : ANN_RD_CHUNK;  // LDS lists sized to the row
@@ -782,7 +811,7 @@ static void launch_rows(const QParams &P, size_t Q, const FT *y, int alias, cons
 #define CALL(DD)                                                                                         \
   do {                                                                                                   \
     allow_lds(row_dists_kernel<DD, MODE>, smem);                                                         \
-    hipLaunchKernelGGL((row_dists_kernel<DD, MODE>), dim3(grid, split), dim3(block), smem, s, P, (int)Q, y, \
+    hipLaunchKernelGGL((row_dists_kernel<DD, MODE>), dim3(grid, split), dim3(block), smem, s, P, kq, y, \
                        alias, codes, qidx, xbase, len, top_i, top_d, ids, dist, rows_done, live_rows,        \
                        (u32)nq, chunk, live_off);                                                            \
   } while (0)
@@ -906,7 +935,7 @@ static long finalize_and_fallback(annhip_index *ix, const QParams &P, size_t Q, 
                                   const u32 *codes, int mode, const FT *cand_d, const u32 *cand_i,
                                   const u32 *nvt, u32 *top_i, FT *top_d, int ostride, int ooff, DevBuf &flist,
                                   DevBuf &xids, DevBuf &xd, u32 *d_fcount, unsigned long long *rows_done,
-                                  unsigned long long *exact_total, bool device_driven, hipStream_t s) {
+                                  unsigned long long *exact_total, bool device_driven, hipStream_t s, size_t qstride = 0) {
   const int K1 = P.k + 1;
   u32 nflag = 0;
   u32 *fl = (u32 *)flist.need(sizeof(u32) * Q);
@@ -929,7 +958,7 @@ static long finalize_and_fallback(annhip_index *ix, const QParams &P, size_t Q, 
       for (size_t p0 = 0; p0 < Q; p0 += R) {
         const size_t nq = std::min(R, Q - p0);
         launch_rows<MODE_TABLE>(P, Q, y, alias, codes, fl + p0, 0, nq, P.Lc1, NULL, NULL, ids, dist, rows_done, s, d_fcount,
-                                (u32)p0);
+                                (u32)p0, qstride);
         launch_exact_select(P.L1, P.Lc1, P.Lc1, P.k, nq, ids, dist, fl + p0, 0, top_i, top_d, ostride, ooff, s, d_fcount,
                             NULL, 1024, (u32)p0);
       }
@@ -953,7 +982,7 @@ static long finalize_and_fallback(annhip_index *ix, const QParams &P, size_t Q, 
     u32 *ids = (u32 *)xids.need(sizeof(u32) * nq * P.Lc1);
     FT *dist = (FT *)xd.need(sizeof(FT) * nq * P.Lc1);
     const u32 *qidx = mode == 0 ? fl + q0 : NULL;
-    launch_rows<MODE_TABLE>(P, Q, y, alias, codes, qidx, (u32)q0, nq, P.Lc1, NULL, NULL, ids, dist, rows_done, s);
+    launch_rows<MODE_TABLE>(P, Q, y, alias, codes, qidx, (u32)q0, nq, P.Lc1, NULL, NULL, ids, dist, rows_done, s, NULL, 0, qstride);
     launch_exact_select(P.L1, P.Lc1, P.Lc1, P.k, nq, ids, dist, qidx, (u32)q0, top_i, top_d, ostride, ooff, s);
   }
   return (long)nflag;
@@ -984,8 +1013,11 @@ static size_t codes_needed(const annhip_index *ix, size_t Q) {
 // ----------------------------------------------------------------------------- query
 // codes_ready: ws.codes already holds the hash codes of this batch (query_gpu computes them chunk by chunk while the
 // batch is still arriving over PCIe)
+// codes_ext / qstride: the batch is a SLICE of a larger one whose codes (try-major reads, stride qstride) the caller holds:
+// codes_ext points at the slice's first query (annhip_query_slice).
 static long query_impl(annhip_index *ix, annhip_workspace &ws, hipStream_t s, size_t Q, const ftype *y_dev, int alias,
-                       int mode, size_t *ids_dev, ftype *dists_dev, bool codes_ready = false) {
+                       int mode, size_t *ids_dev, ftype *dists_dev, bool codes_ready = false, const u32 *codes_ext = NULL,
+                       size_t qstride = 0) {
   if (!Q) return 0;
   if (Q >= 0x7FFFFFFFull / (size_t)(ix->T > 0 ? ix->T : 1)) die("query batch too large");
   const QParams P = make_params(ix);
@@ -996,8 +1028,14 @@ static long query_impl(annhip_index *ix, annhip_workspace &ws, hipStream_t s, si
   if ((u32)k > P.P1) mode = 1;
   std::vector<hipEvent_t> marks_store, *marks = ix->profile ? &marks_store : NULL;
   seg_mark(ix, marks, s);
-  u32 *codes = (u32 *)ws.codes.need(sizeof(u32) * Q * P.T);
-  if (!codes_ready) launch_codes(P, codes_needed(ix, Q), y, codes, s);
+  const u32 *codes = codes_ext;
+  if (!codes_ext) {
+    u32 *own = (u32 *)ws.codes.need(sizeof(u32) * Q * P.T);
+    if (!codes_ready) launch_codes(P, codes_needed(ix, Q), y, own, s);
+    codes = own;
+  } else if (ix->fixed) {
+    die("annhip_query_slice: not available in fixed mode");
+  }
   seg_mark(ix, marks, s);
   u32 *top_i = (u32 *)ws.top_i.need(sizeof(u32) * Q * k);
   FT *top_d = (FT *)ws.top_d.need(sizeof(FT) * Q * k);
@@ -1036,7 +1074,7 @@ static long query_impl(annhip_index *ix, annhip_workspace &ws, hipStream_t s, si
     const bool whole = ix->lo == 0 && ix->hi == ix->n;
     // Measured: +5 % at Q = 1k (launch-bound), neutral at cfg3 (Q = 10k, d = 128), -6 % at Q = 10k, d = 64 -- the tail
     // keeps the workgroup's registers/LDS occupied through a chain of dependent loads.  So: small batches only.
-    const bool want = env().fuse >= 0 ? env().fuse != 0 : Q <= 2048;  // ANN_HIP_FUSE: 0 = never, 1 = whenever possible
+    const bool want = !codes_ext && (env().fuse >= 0 ? env().fuse != 0 : Q <= 2048);  // ANN_HIP_FUSE: 0 = never, 1 = whenever possible
     if (mode == 0 && whole && want && P.Lc2 <= 1024 && Q * xrow <= env().exact_bytes) {
       FT *out_d = dists_dev ? reinterpret_cast<FT *>(dists_dev) : (FT *)ws.out_d.need(sizeof(FT) * Q * k);
       u32 *fl = (u32 *)ws.flist.need(sizeof(u32) * Q);
@@ -1069,12 +1107,13 @@ static long query_impl(annhip_index *ix, annhip_workspace &ws, hipStream_t s, si
     cand_i = (u32 *)ws.cand_i.need(sizeof(u32) * Q * K1);
     nvt = (u32 *)ws.nvt.need(sizeof(u32) * Q);
     u32 *nvo = (u32 *)ws.nvo.need(sizeof(u32) * Q);
-    launch_stage1(ix, P, Q, y, alias, codes, cand_d, cand_i, nvt, nvo, s, ix->h_tries, ix->use_seg);
+    launch_stage1(ix, P, Q, y, alias, codes, cand_d, cand_i, nvt, nvo, s, ix->h_tries, ix->use_seg,
+                  FusedTail{0, 0, NULL, NULL, NULL, NULL, NULL}, NULL, 1, env().s1_slots, qstride);
   }
   seg_mark(ix, marks, s);
   unsigned long long *rows_ctr = ix->profile ? ix->d_rows + 8 : NULL;
   long nflag = finalize_and_fallback(ix, P, Q, y, alias, codes, mode, cand_d, cand_i, nvt, top_i, top_d, k, 0,
-                                     ws.flist, ws.xids, ws.xd, ws.d_fcount, rows_ctr, ix->d_rows + 2, true, s);
+                                     ws.flist, ws.xids, ws.xd, ws.d_fcount, rows_ctr, ix->d_rows + 2, true, s, qstride);
   seg_mark(ix, marks, s);
   // stage 2 (det_results second half, alg.c:314-327)
   FT *out_d = dists_dev ? reinterpret_cast<FT *>(dists_dev) : (FT *)ws.out_d.need(sizeof(FT) * Q * k);
@@ -1141,6 +1180,16 @@ extern "C" void annhip_workspace_destroy(annhip_workspace *ws) {
 extern "C" long annhip_query_on(annhip_index *ix, annhip_workspace *ws, void *hip_stream, size_t Q, const ftype *y_dev,
                                 int alias, int mode, size_t *ids_dev, ftype *dists_dev) {
   return query_impl(ix, ws ? *ws : ix->ws, (hipStream_t)hip_stream, Q, y_dev, alias, mode, ids_dev, dists_dev);
+}
+
+extern "C" long annhip_query_slice(annhip_index *ix, annhip_workspace *ws, void *hip_stream, size_t ycnt, size_t q_lo, size_t nq,
+                                   const ftype *y_slice_dev, const uint32_t *codes_all_dev, int alias, size_t *ids_dev,
+                                   ftype *dists_dev) {
+  if (q_lo + nq > ycnt) die("annhip_query_slice: slice outside the batch");
+  if (alias && q_lo) die("annhip_query_slice: an aliased batch (y == points) cannot be sliced");
+  if (!(ix->lo == 0 && ix->hi == ix->n)) die("annhip_query_slice needs all rows on this device (replica hosts)");
+  return query_impl(ix, ws ? *ws : ix->ws, (hipStream_t)hip_stream, nq, y_slice_dev, alias, 0, ids_dev, dists_dev, false,
+                    codes_all_dev + q_lo, ycnt);
 }
 
 // ----------------------------------------------------------------------------- host-side streaming
@@ -1284,7 +1333,7 @@ extern "C" void annhip_sh_stage1(annhip_index *ix, void *hip_stream, size_t Q, c
   if ((u32)P.k > P.P1) die("annhip_sh_stage1: k exceeds the sorted prefix; use the exact path (annhip_stage1_rows)");
   launch_stage1(ix, P, Q, reinterpret_cast<const FT *>(y_dev), alias, codes_dev, NULL, NULL, nvalid_dev, nown_dev,
                 (hipStream_t)hip_stream, ix->h_tries, ix->use_seg, FusedTail{0, 0, NULL, NULL, NULL, NULL, NULL},
-                reinterpret_cast<Key *>(keys_dev), ix->gather_pieces);
+                reinterpret_cast<Key *>(keys_dev), ix->gather_pieces, ix->gather_slots);
   ix->queries += (double)Q;
 }
 

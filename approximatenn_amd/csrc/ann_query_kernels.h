@@ -41,7 +41,8 @@ struct QParams {
   u32 n, lo, hi;
   int d, k, T, ds;
   u32 L1, P1, Lc1, L2, Lc2;
-  u32 q0;            // stage 1 launched in pieces: the first query of this launch
+  u32 q0, qn;        // stage 1: this launch covers queries [q0, q0 + qn); workgroup b takes q0 + b, q0 + b + grid ...
+                     // (grid == qn: one query per workgroup; a smaller, PERSISTENT grid leaves wave slots to other streams)
   u32 fixed;         // opt-in non-parity mode (annhip_index_set_fixed): a query reads ITS OWN codes (Q2 undone); the host
                      // also sets P1 = Lc1 = L1 (every slot is a candidate, Q1 undone) and no network decides an order
 };
@@ -807,7 +808,6 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
                                                             Key *__restrict__ cand_key) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = lane_id(), w = threadIdx.x >> 6, W = blockDim.x >> 6;
-  const u32 x = blockIdx.x + P.q0;
   // ---- LDS carve-up (mirrored by stage1_lds_bytes on the host)
   unsigned char *sp = smem;
   Key *kbuf_all = reinterpret_cast<Key *>(sp);           sp += sizeof(Key) * (size_t)W * cap;
@@ -832,6 +832,9 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
   u32 *pref = pref_all + (size_t)w * ANN_WAVE;
   const u32 **rptr = rptr_all + (size_t)w * ANN_WAVE;
 
+  for (u32 xi = blockIdx.x; xi < P.qn; xi += gridDim.x) {  // one query per pass (a single pass unless the grid is persistent)
+  const u32 x = xi + P.q0;
+  if (xi != blockIdx.x) __syncthreads();  // the previous query's LDS state has been consumed
   for (int i = threadIdx.x; i < P.T; i += blockDim.x) {
     tries[i] = P.tries[i];
     qcode[i] = P.fixed ? codes[(size_t)x * P.T + i] : codes[(size_t)i * Q + x];  // Q2: read layout [try][query]
@@ -1049,7 +1052,7 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
   __syncthreads();
   if (cnts[3]) {  // exact path later; only the statistics are written here
     if (threadIdx.x == 0) nv_own[x] = cnts[1];
-    return;
+    continue;
   }
   // ---- fused stage 2 (det_results second half, alg.c:314-327) on this query's own workgroup
   {
@@ -1058,6 +1061,7 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
     if (threadIdx.x == 0) nv_own[x] = cnts[1] + cnt2;  // rows gathered for this query, both stages
   }
   }  // FUSED
+  }  // queries of this workgroup
 }
 
 // ---------------------------------------------------------------------------------- stage1_bucket

@@ -97,6 +97,9 @@ class HipEngine:
     def set_gather_pieces(self, pieces):
         self.lib.annhip_index_set_gather_pieces(self.h, int(pieces))
 
+    def set_gather_slots(self, waves_per_simd):
+        self.lib.annhip_index_set_gather_slots(self.h, int(waves_per_simd))
+
     def empty(self, shape, dtype, like):
         return torch.empty(shape, dtype=dtype, device=like.device)
 
@@ -156,7 +159,7 @@ class _Lane:
     """Buffers + stream of one in-flight batch.  Everything is allocated once per batch size: no per-step tensors."""
 
     def __init__(self, stream):
-        self.stream, self.shape, self.busy, self.event, self.need_back = stream, None, False, None, False
+        self.stream, self.shape, self.busy, self.event, self.next, self.seq = stream, None, False, None, 6, 0
         self.ev_in = self.ev_out = None
 
     def ensure(self, eng, y, G, qs, fcap):
@@ -217,8 +220,8 @@ class ShardedQuery:
         self._gather_streams = {}           # CUs left free -> the gathers' stream
         self._lanes = [_Lane(None) for _ in range(max(1, lanes))]
         self.depth = len(self._lanes)       # lanes in use (autotune() may lower it)
-        self.split = os.environ.get("ANN_SHARD_NO_SPLIT") != "1"   # issue a batch in two halves (see submit())
-        self.tuned, self.pieces = None, 1
+        self.split = 0 if os.environ.get("ANN_SHARD_NO_SPLIT") == "1" else 1   # issue order of the stages (see _stage())
+        self.tuned, self.pieces, self.slots = None, 1, 0
         self._next, self._tickets = 0, {}
         self.last_exact = 0
 
@@ -296,11 +299,95 @@ class ShardedQuery:
         return t
 
     # ------------------------------------------------------------------ one step
-    # A batch is enqueued in two halves.  FRONT = hash, all-gather of the codes, the stage-1 gather; BACK = everything
-    # behind the gather (exchanges, merges, exact path, stage 2, networks).  All collectives of a process group run in
-    # ISSUE order on the communicator's one stream, and every collective of BACK(i) waits for gather(i): had BACK(i)
-    # been issued before FRONT(i+1), the codes all-gather of batch i+1 would sit behind it and gather(i+1) could not
-    # start before batch i was nearly done.  So submit(i+1) issues FRONT(i+1) first and only then BACK(i).
+    # A batch goes through six stages, each ending in exactly ONE collective:
+    #   0  hash of the owned query slice              -> all-gather of the codes
+    #   1  stage-1 gather over the owned rows         -> all-to-all of the candidate keys
+    #   2  owner: merge + proof                       -> all-gather of the top-k ids
+    #   3  flagged queries: exact rows                -> MIN all-reduce (fixed size)
+    #   4  their network; stage-2 distances           -> all-to-all of the partial rows
+    #   5  owner: min + network                       -> all-gather of the results
+    # All collectives of a process group execute in ISSUE order on the communicator's one stream, so the order in which
+    # the host issues the stages of the in-flight batches decides what can overlap:
+    #   split = 0   a whole batch at once (stages 0..5 of batch i, then batch i+1)
+    #   split = 1   two halves: submit(i+1) issues stages 0-1 of batch i+1 BEFORE stages 2-5 of batch i -- otherwise the codes
+    #               all-gather of batch i+1 sits behind batch i's exchanges (which all wait for gather i) and gather i+1
+    #               cannot start before batch i is nearly done
+    #   split = 2   STAGE-MAJOR (software pipeline): every submit() advances every in-flight batch by ONE stage --
+    #               stage 0 of the new batch first, then stages 5, 4, 3, 2 of the older ones, then stage 1 (gather + key
+    #               exchange) of the batch hashed one submit earlier, so that a gather never waits for a collective issued
+    #               in the same step.  Needs >= 7 lanes (a batch is in flight for six submits).  On ONE GPU with RCCL
+    #               kernels in the loop (tools/emulate_rank.py --rccl) it measures like split = 1 (1.65-1.75 ms per 8-way
+    #               rank step): there a collective that becomes ready in the middle of a gather completes only when the
+    #               gather drains -- 1.0-1.2 ms of a 1.25 ms gather, also when the gather runs as a persistent grid that
+    #               leaves half of the wave slots free (annhip_index_set_gather_slots), so it is not a placement problem --
+    #               and the rest of its batch's chain (~0.35 ms) runs before the next gather can start.  Whether RCCL
+    #               behaves like that between real ranks only a multi-GPU run can tell: the order is one of the settings
+    #               autotune() measures in place.
+    def _stage(self, L, st):
+        e, G, Q, qs, q_lo, y, alias = self.eng, self.world, L.Q, L.qs, L.q_lo, L.y, L.alias
+        with e.use(L.stream):
+            if st == 0:
+                L.ensure(e, y, G, qs, self.fcap)
+                e.sh_codes(y, q_lo, q_lo + qs, L.codes_slice)
+                self._gather_cat(L.codes_all, L.codes_slice)
+            elif st == 1:
+                if self.exact_all:
+                    L.top_all.fill_(ID_FLAG - (1 << 32))                 # every query takes the exact path
+                    L.top_i.fill_(ID_FLAG - (1 << 32))
+                else:
+                    gs = self._gather_streams[self.reserve_cus] if L.stream is not None else None
+                    if gs is not None:                                   # gathers of all batches: back to back
+                        if L.ev_in is None:
+                            L.ev_in, L.ev_out, L.event = e.new_event(), e.new_event(), e.new_event()
+                        L.ev_in.record(L.stream)
+                        gs.wait_event(L.ev_in)
+                    e.sh_stage1(y, alias, L.codes_all, L.keys, L.nvalid, L.nown, stream=gs)
+                    if gs is not None:
+                        L.ev_out.record(gs)
+                        L.stream.wait_event(L.ev_out)
+                    if self.split != 1:        # (two-half order: the key exchange belongs to the second half)
+                        self._to_owner(L.keys_in, L.keys)
+            elif st == 2:
+                if not self.exact_all:
+                    if self.split == 1:
+                        self._to_owner(L.keys_in, L.keys)
+                    e.sh_merge_finalize(G, Q, q_lo, qs, L.keys_in, L.nvalid, L.top_i, L.top_d)
+                    self._gather_cat(L.top_all, L.top_i)
+            elif st == 3:      # flagged queries: exact stage 1 on the device, one fixed-size MIN all-reduce in the middle
+                e.sh_exact1_begin(y, alias, L.codes_all, L.top_all, self.fcap, L.flist, L.xrows_i, L.xrows_d)
+                self._all_min(L.xrows_d)
+            elif st == 4:
+                e.sh_exact1_end(Q, q_lo, qs, self.fcap, L.flist, L.xrows_i, L.xrows_d, L.top_all, L.top_d_all, L.top_i, L.top_d)
+                e.sh_stage2(y, alias, L.top_all, L.s2, L.flagged)
+                self._to_owner(L.s2_in, L.s2)
+            elif st == 5:
+                e.sh_final(G, Q, q_lo, qs, L.top_i, L.top_d, L.s2_in, L.out_i_slice, L.out_d_slice)
+                self._gather_cat(L.pack_all, L.pack.view(1, -1))
+                # (the packed rows are unpacked in collect(): straight into the 64-bit ids / the returned distances)
+                L.head_host[0:1].copy_(L.flagged[0:1], non_blocking=True)
+                L.head_host[1:2].copy_(L.flist[1:2], non_blocking=True)
+                if L.stream is not None:
+                    if L.event is None:
+                        L.event = e.new_event()
+                    L.event.record(L.stream)
+        L.next = st + 1
+
+    def _advance(self, L, upto):
+        while L.next <= upto:
+            self._stage(L, L.next)
+
+    def _tick(self, new=None):
+        """Stage-major order: one stage for every batch in flight (see above)."""
+        if new is not None:
+            self._stage(new, 0)
+        older = sorted((P for P in self._lanes if P.busy and P is not new and P.next <= 5), key=lambda P: P.seq)
+        for P in older:                       # oldest first: stages 5, 4, 3, 2 ...
+            if P.next >= 2:
+                self._stage(P, P.next)
+        for P in older:                       # ... and last the gather + key exchange of the batch hashed a step ago
+            if P.next == 1:
+                self._stage(P, 1)
+
     def submit(self, y, alias=False):
         """Enqueue one batch (y: [Q,d], identical on every rank).  Returns a ticket for collect()."""
         e, G, r = self.eng, self.world, self.rank
@@ -314,67 +401,33 @@ class ShardedQuery:
         Q = y.shape[0]
         L.y, L.alias, L.Q, L.qs = y, alias, Q, (Q + G - 1) // G
         L.q_lo = r * L.qs
+        L.next, L.seq = 0, self._next
         if L.stream is not None:
             L.stream.wait_stream(torch.cuda.current_stream(y.device))   # y was produced on the caller's stream
-        with e.use(L.stream):
-            L.ensure(e, y, G, L.qs, self.fcap)
-            e.sh_codes(y, L.q_lo, L.q_lo + L.qs, L.codes_slice)
-            self._gather_cat(L.codes_all, L.codes_slice)
-            if not self.exact_all:
-                gs = self._gather_streams[self.reserve_cus] if L.stream is not None else None
-                if gs is not None:                                       # gathers of all batches: back to back
-                    if L.ev_in is None:
-                        L.ev_in, L.ev_out, L.event = e.new_event(), e.new_event(), e.new_event()
-                    L.ev_in.record(L.stream)
-                    gs.wait_event(L.ev_in)
-                e.sh_stage1(y, alias, L.codes_all, L.keys, L.nvalid, L.nown, stream=gs)
-                if gs is not None:
-                    L.ev_out.record(gs)
-                    L.stream.wait_event(L.ev_out)
-        L.busy, L.need_back = True, True
-        if not self.split:                                               # the whole batch at once
-            self._back(L)
-        for P in self._lanes:                                            # the batch submitted before this one
-            if P is not L and P.busy and P.need_back:
-                self._back(P)
+        L.busy = True
+        if self.split >= 2:
+            self._tick(L)
+        else:
+            self._advance(L, 1)
+            if not self.split:                                           # the whole batch at once
+                self._advance(L, 5)
+            for P in self._lanes:                                        # the batch submitted before this one
+                if P is not L and P.busy and P.next <= 5:
+                    self._advance(P, 5)
         t = self._next
         self._tickets[t] = L
         self._next += 1
         return t
 
-    def _back(self, L):
-        e, G, Q, qs, q_lo, y, alias = self.eng, self.world, L.Q, L.qs, L.q_lo, L.y, L.alias
-        with e.use(L.stream):
-            if self.exact_all:
-                L.top_all.fill_(ID_FLAG - (1 << 32))                     # every query takes the exact path
-                L.top_i.fill_(ID_FLAG - (1 << 32))
-            else:
-                self._to_owner(L.keys_in, L.keys)
-                e.sh_merge_finalize(G, Q, q_lo, qs, L.keys_in, L.nvalid, L.top_i, L.top_d)
-                self._gather_cat(L.top_all, L.top_i)
-            # flagged queries: exact stage 1 on the device, one fixed-size MIN all-reduce in the middle
-            e.sh_exact1_begin(y, alias, L.codes_all, L.top_all, self.fcap, L.flist, L.xrows_i, L.xrows_d)
-            self._all_min(L.xrows_d)
-            e.sh_exact1_end(Q, q_lo, qs, self.fcap, L.flist, L.xrows_i, L.xrows_d, L.top_all, L.top_d_all, L.top_i, L.top_d)
-            e.sh_stage2(y, alias, L.top_all, L.s2, L.flagged)
-            self._to_owner(L.s2_in, L.s2)
-            e.sh_final(G, Q, q_lo, qs, L.top_i, L.top_d, L.s2_in, L.out_i_slice, L.out_d_slice)
-            self._gather_cat(L.pack_all, L.pack.view(1, -1))
-            # (the packed rows are unpacked in collect(): straight into the 64-bit ids / the returned distances)
-            L.head_host[0:1].copy_(L.flagged[0:1], non_blocking=True)
-            L.head_host[1:2].copy_(L.flist[1:2], non_blocking=True)
-            if L.stream is not None:
-                if L.event is None:
-                    L.event = e.new_event()
-                L.event.record(L.stream)
-        L.need_back = False
-
     def collect(self, ticket):
         """Wait for the batch, repair flagged queries if there are any, return (ids int64 [Q,k], sq. distances [Q,k])."""
         e = self.eng
         L = self._tickets.pop(ticket)
-        if L.need_back:                       # no later batch was submitted: its second half is still to be issued
-            self._back(L)
+        while L.next <= 5:                    # no later batch was submitted (or fewer than the pipeline is deep): flush
+            if self.split >= 2:
+                self._tick(None)
+            else:
+                self._advance(L, 5)
         if L.event is not None:
             L.event.synchronize()
         nf = int(L.head_host[0])              # flagged queries the device-driven exact path had no room for; the same
@@ -443,7 +496,8 @@ class ShardedQuery:
     # PINNED default: what every job runs unless a measurement inside its time budget finds something faster.  The
     # CU-masked candidates (hipExtStreamCreateWithCUMask) are opt-in: they only ever won the two-lane case.
     PINNED = (3, True, 0, 1)
-    TUNE_CANDIDATES = (PINNED, (3, False, 0, 1), (2, False, 0, 1), (3, True, 0, 4), (3, False, 0, 4), (1, False, 0, 1))
+    STAGEWISE = (7, 2, 0, 1)   # stage-major issue order, hash one step ahead (needs 7 lanes)
+    TUNE_CANDIDATES = (PINNED, STAGEWISE, (3, False, 0, 1), (2, False, 0, 1), (3, True, 0, 4), (3, True, 0, 1, 3), (1, False, 0, 1))
     TUNE_CANDIDATES_MASKED = ((3, True, 8, 1), (3, False, 8, 1), (2, False, 8, 1))
 
     def pump(self, ys, alias=False):
@@ -457,12 +511,15 @@ class ShardedQuery:
             out.append(self.collect(pend.pop(0)))
         return out
 
-    def configure(self, depth, split, reserve_cus=0, pieces=1):
+    def configure(self, depth, split, reserve_cus=0, pieces=1, slots=0):
+        """slots > 0: the stage-1 gather as a persistent grid holding that many waves per SIMD (annhip_index_set_gather_slots)."""
         if any(L.busy for L in self._lanes):
             raise RuntimeError("configure() with batches in flight")
-        self.depth, self.split, self.reserve_cus = max(1, min(int(depth), len(self._lanes))), bool(split), int(reserve_cus)
-        self.pieces = max(1, int(pieces))
+        self.depth, self.split, self.reserve_cus = max(1, min(int(depth), len(self._lanes))), int(split), int(reserve_cus)
+        self.pieces, self.slots = max(1, int(pieces)), max(0, int(slots))
         self.eng.set_gather_pieces(self.pieces)
+        if hasattr(self.eng, "set_gather_slots"):
+            self.eng.set_gather_slots(self.slots)
 
     def _agreed_max(self, value, like):
         """MAX over the ranks of a host float (one tiny all-reduce; every rank gets the same number)."""
@@ -515,13 +572,125 @@ class ShardedQuery:
         best = min(range(len(table)), key=lambda j: table[j])
         self.configure(*cands[best])
         self.tuned = {"depth": self.depth, "split": self.split, "reserve_cus": self.reserve_cus, "pieces": self.pieces,
-                      "ms_per_batch": round(table[best], 4), "pinned_ms_per_batch": round(table[0], 4),
+                      "slots": self.slots, "ms_per_batch": round(table[best], 4), "pinned_ms_per_batch": round(table[0], 4),
                       "tune_s": round(time.perf_counter() - t_start, 2),
                       "table": [{"depth": c[0], "split": c[1], "reserve_cus": c[2], "pieces": c[3],
+                                 "slots": c[4] if len(c) > 4 else 0,
                                  "ms": (round(v, 4) if v != float("inf") else None)} for c, v in zip(cands, table)]}
         if stopped:
             self.tuned["stopped"] = stopped
         return self.tuned
+
+
+class ReplicaQuery:
+    """Query-sharded query(): every rank holds ALL rows and the whole index and answers a contiguous slice of each batch.
+
+    SURVEY 8(e) names this split as the alternative to row sharding; 20 GB of cfg4's points fit every 288-GB GPU.  Results
+    depend on the whole batch (query x reads hash codes of other queries, Q2), so one exchange remains: every rank hashes
+    its slice, ONE all-gather gives everybody the codes of all queries (4*T bytes per query), then annhip_query_slice runs
+    the single-GPU path -- the whole-index gather at its full roofline fraction, the fused stage 2, the device-driven exact
+    path -- on the slice.  gather=True all-gathers the results (k*(8+s) bytes per query) so that every rank returns the
+    whole batch; otherwise a rank returns its own slice.  Bit-identical to the single-GPU answer.
+    Up to `lanes` batches are in flight (submit / collect / pump), each on its own stream and workspace."""
+
+    def __init__(self, ix, dist=None, group=None, lanes=2, gather=True):
+        self.ix, self.lib, self.group, self.gather = ix, ix.lib, group, gather
+        self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size(group) > 1) else None
+        self.world = self.dist.get_world_size(group) if self.dist else 1
+        self.rank = self.dist.get_rank(group) if self.dist else 0
+        self._via_cpu = bool(self.dist) and self.dist.get_backend(group) == "gloo"
+        self.ft = torch.float32 if ix.prec == "f32" else torch.float64
+        self.depth = max(1, int(lanes))
+        self._lanes = [dict(stream=None, ws=None, busy=False, shape=None) for _ in range(self.depth)]
+        self._next, self._tickets = 0, {}
+
+    def _all_gather(self, out, inp):
+        if not self.dist:
+            out.copy_(inp.reshape(out.shape))
+        elif self._via_cpu and inp.is_cuda:
+            o = torch.empty(out.shape, dtype=out.dtype)
+            self.dist.all_gather_into_tensor(o, inp.cpu().contiguous(), group=self.group)
+            out.copy_(o)
+        else:
+            self.dist.all_gather_into_tensor(out, inp, group=self.group)
+
+    def submit(self, y, alias=False):
+        assert y.is_cuda and y.is_contiguous() and y.dtype == self.ft and y.shape[1] == self.ix.d
+        if alias and self.world > 1:
+            raise ValueError("an aliased batch (y == points) cannot be query-sharded")
+        L = self._lanes[self._next % self.depth]
+        if L["busy"]:
+            raise RuntimeError("every lane is in flight: collect() the oldest ticket first")
+        ix, G, r, k, T = self.ix, self.world, self.rank, self.ix.k, self.ix.tries
+        Q = y.shape[0]
+        qs = (Q + G - 1) // G
+        q_lo = min(Q, r * qs)
+        nq = min(qs, Q - q_lo)
+        if L["stream"] is None:
+            L["stream"], L["ws"] = torch.cuda.Stream(device=y.device), ix.workspace()
+        if L["shape"] != (Q, G):
+            e = lambda shape, dt: torch.empty(shape, dtype=dt, device=y.device)  # noqa: E731
+            es = 4 if self.ft == torch.float32 else 8
+            L["codes_slice"], L["codes_all"] = e((qs * T,), torch.int32), e((qs * G * T,), torch.int32)
+            L["nb_i"], L["nb_d"] = qs * k * 8, qs * k * es
+            per = (L["nb_i"] + L["nb_d"] + 15) // 16 * 16          # this rank's results: ids, then distances, padded
+            L["pack"], L["pack_all"] = e((per,), torch.uint8), e((G, per), torch.uint8)
+            L["ids"] = L["pack"][: L["nb_i"]].view(torch.int64).view(qs, k)
+            L["dd"] = L["pack"][L["nb_i"]: L["nb_i"] + L["nb_d"]].view(self.ft).view(qs, k)
+            L["shape"] = (Q, G)
+        L.update(y=y, Q=Q, qs=qs, nq=nq)
+        st = L["stream"]
+        st.wait_stream(torch.cuda.current_stream(y.device))
+        with torch.cuda.stream(st):
+            self.lib.annhip_sh_codes(ix.h, st.cuda_stream, Q, y.data_ptr(), q_lo, q_lo + qs, L["codes_slice"].data_ptr())
+            self._all_gather(L["codes_all"], L["codes_slice"])
+            if nq:
+                self.lib.annhip_query_slice(ix.h, L["ws"], st.cuda_stream, Q, q_lo, nq, y[q_lo:].data_ptr(),
+                                            L["codes_all"].data_ptr(), int(alias), L["ids"].data_ptr(), L["dd"].data_ptr())
+            if self.gather:
+                self._all_gather(L["pack_all"], L["pack"].view(1, -1))
+        L["busy"] = True
+        t = self._next
+        self._tickets[t] = L
+        self._next += 1
+        return t
+
+    def collect(self, ticket):
+        """(ids int64 [Q,k], squared distances [Q,k]) of the whole batch (gather=True) or of this rank's slice."""
+        L = self._tickets.pop(ticket)
+        k, Q, qs, G = self.ix.k, L["Q"], L["qs"], self.world
+        cur = torch.cuda.current_stream(L["y"].device)
+        if self.gather:
+            ids = torch.empty((G * qs, k), dtype=torch.int64, device=L["y"].device)
+            dd = torch.empty((G * qs, k), dtype=self.ft, device=L["y"].device)
+            L["stream"].wait_stream(cur)
+            with torch.cuda.stream(L["stream"]):
+                ids.view(G, qs * k).copy_(L["pack_all"][:, : L["nb_i"]].view(torch.int64))
+                dd.view(G, qs * k).copy_(L["pack_all"][:, L["nb_i"]: L["nb_i"] + L["nb_d"]].view(self.ft))
+            ids, dd = ids[:Q], dd[:Q]
+        else:
+            ids, dd = torch.empty((L["nq"], k), dtype=torch.int64, device=L["y"].device), \
+                torch.empty((L["nq"], k), dtype=self.ft, device=L["y"].device)
+            L["stream"].wait_stream(cur)
+            with torch.cuda.stream(L["stream"]):
+                ids.copy_(L["ids"][: L["nq"]])
+                dd.copy_(L["dd"][: L["nq"]])
+        cur.wait_stream(L["stream"])
+        L["busy"], L["y"] = False, None
+        return ids, dd
+
+    def query(self, y, alias=False):
+        return self.collect(self.submit(y, alias))
+
+    def pump(self, ys, alias=False):
+        out, pend = [], []
+        for y in ys:
+            pend.append(self.submit(y, alias))
+            if len(pend) >= self.depth:
+                out.append(self.collect(pend.pop(0)))
+        while pend:
+            out.append(self.collect(pend.pop(0)))
+        return out
 
 
 def same_everywhere(dist, values, what="values", group=None, device="cpu"):

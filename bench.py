@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--fixed-mode-timing", action="store_true",
                     help="also time one full batch in the opt-in fixed mode (recall_sample.fixed_mode.ms_per_step)")
     ap.add_argument("--no-strong-extra", action="store_true", help="N > 1: skip the fixed-batch (strong scaling) extra")
+    ap.add_argument("--no-replicas-extra", action="store_true",
+                    help="N > 1: skip the query-sharded (every GPU holds all rows) extra reported under 'replicas'")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--tune-seconds", type=float, default=20.0,
                     help="N > 1: wall-clock budget of the in-place schedule measurement before the warm-up (0 = keep the "
@@ -258,9 +260,10 @@ def main():
         with park_random():
             shard = points[lo:hi].clone()
             ix.reshard(shard, lo, hi)
-            del points
+            if args.no_replicas_extra:
+                del points
             torch.cuda.empty_cache()
-        runner = ShardedQuery(ix, dist, lanes=3)   # exchange agreed on by all ranks at start-up (all-to-all, else all-gather)
+        runner = ShardedQuery(ix, dist, lanes=7)   # exchange agreed on by all ranks at start-up (all-to-all, else all-gather)
         # Up to three batches in flight: the exchanges of batch i run under the gathers of i+1, i+2.  The job starts from
         # ONE pinned schedule (ShardedQuery.PINNED); lanes, issue order and launches per gather are then measured in
         # place within --tune-seconds of wall clock (untimed batches before the warm-up, every decision agreed on by
@@ -293,12 +296,12 @@ def main():
         if sharded:
             dist.barrier()
 
-    def timed(ys):
+    def timed(ys, run=None):
         """barrier + synchronize, run, synchronize + barrier; max over ranks."""
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        run_steps(ys)
+        (run or run_steps)(ys)
         submit = time.perf_counter() - t0
         torch.cuda.synchronize()
         barrier()
@@ -370,9 +373,9 @@ def main():
         line["config"]["schedule"] = runner.tuned or {"depth": runner.depth, "split": runner.split,
                                                       "reserve_cus": runner.reserve_cus, "pieces": runner.pieces,
                                                       "pinned": True}
-        line["config"]["note"] = ("steps are pipelined (up to 3 batches in flight, all K steps complete inside the timed "
+        line["config"]["note"] = ("steps are pipelined (%d batches in flight, all K steps complete inside the timed "
                                   "region); the like-for-like single-GPU figure is the N=1 line's `overlap.value` (2 batches "
-                                  "in flight), its `value` is strictly serial")
+                                  "in flight), its `value` is strictly serial" % runner.depth)
 
     # ---- N > 1 extra: strong scaling -- the batch FIXED at --queries in total (10k), sharded the same way
     if sharded and not args.no_strong_extra:
@@ -387,6 +390,22 @@ def main():
                           "schedule": {k_: v for k_, v in (runner.tuned or {}).items() if k_ != "table"},
                           "note": "same job with the batch fixed at %d queries in total (results differ from the weak "
                                   "run's: they depend on the batch, SURVEY Q2)" % Qs}
+
+    # ---- N > 1 extra: the other way to split the job: every GPU keeps ALL rows (cfg4's 20 GB fit each
+    #      288-GB GPU) and answers 1/N of the queries of every batch; one all-gather of the hash codes is the only exchange
+    #      before the results.  Not the mandated row-sharded line -- the bound that line should be judged against.
+    if sharded and not args.no_replicas_extra:
+        from approximatenn_amd.sharded import ReplicaQuery
+        with park_random():
+            ix.reshard(points, 0, n)            # all rows again
+            rq = ReplicaQuery(ix, dist, lanes=2, gather=True)
+        rq.pump(batches[:max(args.warmup, 2)])
+        el_r, _ = timed(batches[args.warmup:], rq.pump)
+        line["replicas"] = {"queries_per_step_total": Q, "value": round(Q * args.steps / el_r, 1), "unit": "queries/s",
+                            "ms_per_step": round(el_r / args.steps * 1e3, 4), "batches_in_flight": rq.depth,
+                            "note": "query-sharded: every GPU holds all %d rows and answers Q/N queries of each batch; "
+                                    "exchanges per step: all-gather of the hash codes (%d B/query), all-gather of the "
+                                    "results; same results" % (n, 4 * T)}
 
     # ---- extra: the same K steps with consecutive batches overlapped on two streams (annhip_query_on); reported
     #      beside `value`, never instead of it: per-launch kernel times are not meaningful while gathers overlap

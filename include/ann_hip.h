@@ -36,6 +36,11 @@ void annhip_index_set_stream(annhip_index *ix, void *hip_stream);
 /* annhip_sh_stage1 launches its gather in `pieces` kernels over consecutive query ranges (default 1).  Same results;
  * the launch boundaries are where workgroups of other streams -- RCCL's in particular -- find free compute units. */
 void annhip_index_set_gather_pieces(annhip_index *ix, int pieces);
+/* annhip_sh_stage1 as a PERSISTENT grid: at most waves_per_simd of the gather's waves on every SIMD, the workgroups walk
+ * the queries themselves (0 = one workgroup per query, the default).  The gather kernel fits 4 waves per SIMD; with 3
+ * one slot per SIMD is always free, so workgroups of other streams (the other batches' small kernels, RCCL) start at
+ * once instead of waiting for the gather to drain.  Same results. */
+void annhip_index_set_gather_slots(annhip_index *ix, int waves_per_simd);
 /* Opt-in "fixed" query mode (default 0 = the reference's results, bit for bit).  With 1, annhip_query / annhip_query_on
  * on this index (whole index on one device) undo two accidents of the reference that cost most of its recall: a query
  * looks up the buckets of ITS OWN hash codes (the reference reads code[i*Q+x] from an array written as [x*T+i],
@@ -135,6 +140,15 @@ annhip_workspace *annhip_workspace_create(annhip_index *ix);
 void annhip_workspace_destroy(annhip_workspace *ws);
 long annhip_query_on(annhip_index *ix, annhip_workspace *ws, void *hip_stream, size_t ycnt, const ftype *y_dev,
                      int alias, int mode, size_t *ids_dev, ftype *dists_dev);
+
+/* Query-sharded ("replica") hosts: every device holds ALL rows and the whole index, and answers a contiguous slice of every
+ * batch.  Results depend on the whole batch (query x reads hash codes of other queries), so the codes of all
+ * ycnt queries must be known everywhere: each device hashes its slice (annhip_sh_codes), ONE all-gather makes
+ * codes_all_dev u32[ycnt*tries] ([q*tries+t]) -- the only exchange of the step -- and annhip_query_slice answers queries
+ * [q_lo, q_lo+nq): y_slice_dev = their rows, ids_dev size_t[nq][k], dists_dev ftype[nq][k].  Same results as annhip_query
+ * on the whole batch.  alias only with q_lo == 0.  SURVEY 8(e) names this split as the alternative to row sharding. */
+long annhip_query_slice(annhip_index *ix, annhip_workspace *ws, void *hip_stream, size_t ycnt, size_t q_lo, size_t nq,
+                        const ftype *y_slice_dev, const uint32_t *codes_all_dev, int alias, size_t *ids_dev, ftype *dists_dev);
 
 /* Host-resident batches, pipelined: `lanes` batches may be in flight, each with pinned staging buffers, a workspace
  * and a HIP stream, so uploads, kernels and downloads of consecutive batches overlap (query_gpu serialises them and

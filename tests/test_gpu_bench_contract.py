@@ -67,6 +67,8 @@ def test_bench_multi_rank_branch_two_ranks_sharing_the_gpu():
     assert "cpu_baseline" not in d          # rank 0 at N=1 only
     s = d["strong"]                         # the same job with the batch fixed at --queries in total
     assert s["queries_per_step_total"] == 1000 and s["value"] > 0
+    r = d["replicas"]                       # the query-sharded alternative (every GPU holds all rows), beside the mandated line
+    assert r["queries_per_step_total"] == 2000 and r["value"] > 0
 
 
 def test_bench_launches_its_own_ranks():

@@ -279,3 +279,44 @@ class _Proxy:
 
     def __getattr__(self, name):
         return getattr(self._td, name)
+
+
+@pytest.mark.parametrize("name,world", [("pow2_d128_f32", 2), ("pow2_d64_f32", 3), ("defaults_d80_f64", 2), ("pow2_d32_f32", 8),
+                                        ("one_try_one_query_f32", 2)])
+def test_replica_hosts_match_golden(name, world):
+    """Query-sharded hosts (approximatenn_amd.sharded.ReplicaQuery, annhip_query_slice): every rank holds all rows, hashes its
+    slice, ONE all-gather of the codes, each rank answers its slice with the single-GPU path; results all-gathered.  Every
+    rank must return the reference's answer for the whole batch (results depend on the other queries' codes, Q2)."""
+    from approximatenn_amd.sharded import ReplicaQuery
+    g = load_golden(name)
+    save = A.Save.from_dict(g["prec"], g["save"])
+    pts = torch.from_numpy(np.ascontiguousarray(g["points"])).cuda()
+    yt = torch.from_numpy(np.ascontiguousarray(g["y"])).cuda()
+    td = ThreadDist(world)
+    results, errors = [None] * world, []
+
+    def work(rank):
+        try:
+            td.tl.rank = rank
+            ix = A.Index.from_save(save, pts)
+            rq = ReplicaQuery(ix, td, lanes=2)
+            res = rq.pump([yt, yt, yt])
+            own = ReplicaQuery(ix, td, lanes=1, gather=False).query(yt)
+            torch.cuda.synchronize()
+            results[rank] = ([(i.cpu().numpy().astype(np.uint64), d_.cpu().numpy()) for i, d_ in res],
+                             (own[0].cpu().numpy().astype(np.uint64), own[1].cpu().numpy()))
+            ix.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            td.bar.abort()
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
+    Q = len(g["y"])
+    qs = (Q + world - 1) // world
+    for rank, (full, own) in enumerate(results):
+        for ids, dd in full:
+            assert np.array_equal(ids, g["query_ids"]) and bits_equal(dd, g["query_dists"])
+        lo, hi = min(Q, rank * qs), min(Q, rank * qs + qs)
+        assert np.array_equal(own[0], g["query_ids"][lo:hi]) and bits_equal(own[1], g["query_dists"][lo:hi])

@@ -98,6 +98,17 @@ def _worker_modes(rank, world, case, mode):
         assert len(res) == 4
         for ids, dd in res:
             assert np.array_equal(ids.numpy().astype(np.uint64), want_ids) and bits_equal(dd.numpy(), want_d)
+    elif mode == "stagewise":    # stage-major issue order (split = 2): seven lanes, a batch advances one stage per submit
+        sq = ShardedQuery(eng, dist, lanes=7)
+        sq.configure(7, 2, 0, 1)
+        res = sq.pump([yt] * 10)                       # steady state: collect() finds its batch finished
+        assert len(res) == 10
+        for ids, dd in res:
+            assert np.array_equal(ids.numpy().astype(np.uint64), want_ids) and bits_equal(dd.numpy(), want_d)
+        t0, t1 = sq.submit(yt), sq.submit(yt)          # fewer batches than the pipeline is deep: collect() flushes
+        ids, dd = sq.collect(t0)
+        ids1, dd1 = sq.collect(t1)
+        assert np.array_equal(ids1.numpy(), ids.numpy()) and bits_equal(dd1.numpy(), dd.numpy())
     elif mode == "autotune_budget":   # no budget left after the pinned candidate: every rank stops there, together
         sq = ShardedQuery(eng, dist, lanes=3)
         tuned = sq.autotune(yt, batches=2, budget_s=0.0)
@@ -112,7 +123,8 @@ def _worker_modes(rank, world, case, mode):
 
 @pytest.mark.parametrize("world,case,mode", [(2, "tiny_appendixA_f32", "allgather"), (3, "few_candidates_f64", "allgather"),
                                              (2, "odd_everything_f32", "exact"), (3, "tiny_appendixA_f32", "pipelined"), (2, "tiny_appendixA_f32", "autotune"),
-                                             (2, "tiny_appendixA_f32", "autotune_budget")])
+                                             (2, "tiny_appendixA_f32", "autotune_budget"), (2, "tiny_appendixA_f32", "stagewise"),
+                                             (3, "odd_everything_f32", "stagewise")])
 def test_sharded_query_modes(world, case, mode):
     port = 29500 + (os.getpid() + hash((case, mode))) % 2000
     mp.spawn(_worker, args=(world, port, case, mode), nprocs=world, join=True)

@@ -33,6 +33,12 @@ ap.add_argument("--lanes", type=int, default=3)
 ap.add_argument("--steps", type=int, default=12)
 ap.add_argument("--rccl", action="store_true")
 ap.add_argument("--tune", action="store_true")
+ap.add_argument("--schedules", type=str, default="",
+                help="semicolon list of depth,split,reserve,pieces[,slots] settings to time (ShardedQuery.configure); "
+                     "split 2 = stage-major issue order")
+ap.add_argument("--slots", type=str, default="",
+                help="comma list: also time the pipelined step with the gather as a persistent grid of that many waves per "
+                     "SIMD (annhip_index_set_gather_slots; 0 = one workgroup per query)")
 args = ap.parse_args()
 
 real = None
@@ -133,6 +139,35 @@ for G in [int(g) for g in args.worlds.split(",")]:
             while pend:
                 sq.collect(pend.pop(0))
         label = "submit/collect, %d lanes" % lanes_used
+    if G > 1 and args.schedules:
+        for sch in args.schedules.split(";"):
+            c = [int(v) for v in sch.split(",")]
+            sq.configure(*c)
+            keep, lanes_used = lanes_used, sq.depth
+            run_all(ys[:8])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_all(ys[4:])
+            torch.cuda.synchronize()
+            print("   G=%d schedule %s: per-rank step %.3f ms" % (G, sch, (time.perf_counter() - t0) / args.steps * 1e3), flush=True)
+            lanes_used = keep
+        fin = os.environ.get("EMUL_FINAL_SCHEDULE")
+        if fin:
+            sq.configure(*[int(v) for v in fin.split(",")])
+            lanes_used = sq.depth
+        else:
+            sq.configure(lanes_used, 1, 0, 1, 0)
+    if G > 1 and args.slots:
+        for sl in [int(v) for v in args.slots.split(",")]:
+            sq.configure(lanes_used, sq.split, sq.reserve_cus, sq.pieces, sl)
+            run_all(ys[:4])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_all(ys[4:])
+            torch.cuda.synchronize()
+            print("   G=%d gather slots %d waves/SIMD: per-rank step %.3f ms" % (G, sl, (time.perf_counter() - t0) / args.steps * 1e3),
+                  flush=True)
+        sq.configure(lanes_used, sq.split, sq.reserve_cus, sq.pieces, int(os.environ.get("EMUL_FINAL_SLOTS", "0")))
     run_all(ys[:4])
     torch.cuda.synchronize()
     if G > 1:
