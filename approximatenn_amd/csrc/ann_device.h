@@ -327,6 +327,11 @@ struct OcCode {
   static constexpr bool UA = D == ANN_D_UNALIGNED || (FOLD > 0 && !GEN);
   static constexpr int C = (D < 0 && !GEN && !UA) ? ((-D) % 16) : 1;  // 16-byte chunks per lane (1 in the element-wise layouts)
   static constexpr int OC = (D < 0 && !GEN && !UA) ? ((-D) / 16) : 0;
+  // Candidate rows are read once per query batch, hence non-temporal loads -- unless a row is not a whole number of
+  // 128-byte lines: its lines are then touched by two different load instructions, and with non-temporal loads the second
+  // touch goes to memory again.  Pure random-row gather, 320-byte rows (d = 80 float, the reference drivers' default):
+  // 4.5-4.75 TB/s of row bytes non-temporal, 5.2-5.3 TB/s cached (tools/readbw.hip); 512-byte rows: 6.8 vs 6.3.
+  static constexpr bool NT_ROWS = OC == 0 || (OC * C * 16) % 128 == 0;
 };
 template <int D>
 struct RowChunks<D, false> {

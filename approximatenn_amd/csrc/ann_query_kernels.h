@@ -51,6 +51,9 @@ struct QParams {
 #ifndef ANN_S1_PREFETCH
 #define ANN_S1_PREFETCH 3  // row passes per wave kept in flight + 1 (gather_select)
 #endif
+#ifndef ANN_S1_PREFETCH_OC
+#define ANN_S1_PREFETCH_OC 2  // the same for the oc-lanes-per-row layouts (d = 80, 96, 160 ...): d = 80 measured 2 / 3 / 4: 69.8 / 66.1 / 63 % of peak (124 / 143 VGPRs)
+#endif
 
 // One 16-byte chunk of a gathered point row.  NT: query batches read each candidate row once and never again,
 // so the load is marked non-temporal and does not displace the re-used bucket tables / graph in L2 and the
@@ -464,38 +467,50 @@ __device__ __forceinline__ void gather_select(const QParams &P, const u32 *list,
     const FoldPlan fp(P.d);
     gather_fold<OcCode<D>::FOLD>(P, fp, list, cnt, alias, x, yrow, S);
   } else if constexpr (D < 0 && !OcCode<D>::GEN) {
+    // the same ring of PF row buffers as the power-of-two layout: passes i+1 .. i+PF-1 are in flight while pass i is
+    // reduced (one pass = rpw rows of oc lanes x C chunks; d = 80: 12 rows = 3.8 KB).  With a single pass of lookahead
+    // the d = 80 gather ran at 2.7 waves per SIMD's worth of requests: 4.0 TB/s against 5.8 at d = 64.
     constexpr int C = OcCode<D>::C, OC = OcCode<D>::OC;
+    constexpr int PF = ANN_S1_PREFETCH_OC;
     const OcLanes<D> ol(P.d, lane);
     const int oc = ol.oc, rpw = ol.rpw, g = ol.g, p = ol.p;  // lanes with !ol.valid have no row
-    VT bn[C];
-    u32 idn = 0;
-    if (cnt > 0) {
-      idn = list[(ol.valid && g < cnt) ? g : 0];
-      const FT *rp = P.points + (size_t)(idn - P.lo) * P.d;
+    VT buf[PF][C];
+    u32 idb[PF];
 #pragma unroll
-      for (int c = 0; c < C; c++) bn[c] = oc_load_chunk<D, true>(rp, p + c * oc, P.d);
-    }
-    for (int base = 0; base < cnt; base += rpw) {
-      VT b[C];
+    for (int s = 0; s < PF; s++) {
+      const int first = s * rpw;
+      idb[s] = 0;
+      if (first < cnt) {
+        idb[s] = list[(ol.valid && first + g < cnt) ? first + g : first];
+        const FT *rp = P.points + (size_t)(idb[s] - P.lo) * P.d;
 #pragma unroll
-      for (int c = 0; c < C; c++) b[c] = bn[c];
-      const u32 id = idn;
-      const bool act = ol.valid && base + g < cnt && !(alias && id == x);
-      const int nb = base + rpw;
-      if (nb < cnt) {
-        idn = list[(ol.valid && nb + g < cnt) ? nb + g : nb];
-        const FT *rp = P.points + (size_t)(idn - P.lo) * P.d;
-#pragma unroll
-        for (int c = 0; c < C; c++) bn[c] = oc_load_chunk<D, true>(rp, p + c * oc, P.d);
+        for (int c = 0; c < C; c++) buf[s][c] = oc_load_chunk<D, OcCode<D>::NT_ROWS>(rp, p + c * oc, P.d);
       }
-      const FT dist = row_reduce_oc<C, ROW_SQDIFF, OC>(a, b, oc, p, oc_tree_len<D>(P.d));
-      const Key key = key_make(dist, id);
-      const bool pass = act && p == 0 && key_less(key, S.tau);
-      const u64 mm = __ballot(pass);
-      if (mm) {
-        if (pass) S.kbuf[S.kcnt + mask_rank(mm)] = key;
-        S.kcnt += __popcll(mm);
-        if (S.kcnt + rpw > S.cap) sel_shrink(S);
+    }
+    for (int base = 0; base < cnt; base += PF * rpw) {
+#pragma unroll
+      for (int s = 0; s < PF; s++) {
+        const int cur = base + s * rpw;
+        if (cur < cnt) {  // wave-uniform
+          const u32 id = idb[s];
+          const bool act = ol.valid && cur + g < cnt && !(alias && id == x);
+          const FT dist = row_reduce_oc<C, ROW_SQDIFF, OC>(a, buf[s], oc, p, oc_tree_len<D>(P.d));
+          const int nb = cur + PF * rpw;
+          if (nb < cnt) {
+            idb[s] = list[(ol.valid && nb + g < cnt) ? nb + g : nb];
+            const FT *rp = P.points + (size_t)(idb[s] - P.lo) * P.d;
+#pragma unroll
+            for (int c = 0; c < C; c++) buf[s][c] = oc_load_chunk<D, OcCode<D>::NT_ROWS>(rp, p + c * oc, P.d);
+          }
+          const Key key = key_make(dist, id);
+          const bool pass = act && p == 0 && key_less(key, S.tau);
+          const u64 mm = __ballot(pass);
+          if (mm) {
+            if (pass) S.kbuf[S.kcnt + mask_rank(mm)] = key;
+            S.kcnt += __popcll(mm);
+            if (S.kcnt + rpw > S.cap) sel_shrink(S);
+          }
+        }
       }
     }
   } else {
@@ -571,7 +586,7 @@ __device__ __forceinline__ u32 stage2_in_workgroup(const QParams &P, u32 x, int 
       const FT *rp = P.points + (size_t)(id - P.lo) * P.d;
       VT b[C];
 #pragma unroll
-      for (int c = 0; c < C; c++) b[c] = oc_load_chunk<D, true>(rp, p + c * oc, P.d);
+      for (int c = 0; c < C; c++) b[c] = oc_load_chunk<D, OcCode<D>::NT_ROWS>(rp, p + c * oc, P.d);
       const FT dist = row_reduce_oc<C, ROW_SQDIFF, OC>(a, b, oc, p, oc_tree_len<D>(P.d));
       if (act && p == 0) t_dist[t_slot[r]] = dist;
     }
@@ -1399,7 +1414,7 @@ __global__ __launch_bounds__(256) void row_dists_kernel(QParams P, int Q, const 
         const FT *rp = P.points + (size_t)(id - P.lo) * P.d;
         VT b[C];
 #pragma unroll
-        for (int c = 0; c < C; c++) b[c] = oc_load_chunk<D, true>(rp, p + c * oc, P.d);
+        for (int c = 0; c < C; c++) b[c] = oc_load_chunk<D, OcCode<D>::NT_ROWS>(rp, p + c * oc, P.d);
         const FT dist = row_reduce_oc<C, ROW_SQDIFF, OC>(a, b, oc, p, oc_tree_len<D>(P.d));
         if (act && p == 0) dist_row[lslot[r]] = dist;
       }

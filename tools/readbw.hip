@@ -38,6 +38,27 @@ __global__ __launch_bounds__(256) void gather(const v4 *p, size_t nrows, size_t 
   }
   if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[0] = 1;
 }
+// random 320-byte rows (the reference drivers' default d = 80 in float): 5 lanes per row, 4 x 16 B each, lane p takes chunks
+// p, p+5, p+10, p+15 (the static oc = 5 layout of stage 1), 12 rows per wave pass; every row touches exactly 3 128-byte lines
+template <bool NT>
+__global__ __launch_bounds__(256) void gather320(const v4 *p, size_t nrows, size_t per_wave, float *out) {
+  const int lane = threadIdx.x & 63, g = lane / 5, q = lane % 5;
+  size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  v4 acc = {0, 0, 0, 0};
+  unsigned long long h = wave * 0x9E3779B97F4A7C15ull + 12345;
+  for (size_t it = 0; it < per_wave; it++) {
+    h = h * 6364136223846793005ull + 1442695040888963407ull;
+    unsigned long long hh = h + g * 0xD1B54A32D192ED03ull;
+    hh ^= hh >> 29; hh *= 0xBF58476D1CE4E5B9ull; hh ^= hh >> 32;
+    size_t row = hh % nrows;
+    const v4 *rp = p + row * 20 + q;
+    if (lane < 60) {
+#pragma unroll
+      for (int c = 0; c < 4; c++) acc += NT ? __builtin_nontemporal_load(rp + c * 5) : rp[c * 5];
+    }
+  }
+  if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[0] = 1;
+}
 int main() {
   size_t bytes = (size_t)5120 << 20;  // 5 GiB, like the cfg3 point matrix
   v4 *p; float *out;
@@ -63,6 +84,14 @@ int main() {
     char nm[96];
     snprintf(nm, 96, "random 512B rows cached  %2d waves/CU", wpc); time([&] { gather<false><<<blocks, 256>>>(p, nrows, per_wave, out); }, nm, gb);
     snprintf(nm, 96, "random 512B rows nt      %2d waves/CU", wpc); time([&] { gather<true><<<blocks, 256>>>(p, nrows, per_wave, out); }, nm, gb);
+  }
+  size_t nrows320 = bytes / 320;
+  for (int wpc : {8, 16, 24, 32}) {
+    int blocks = 256 * wpc / 4; size_t waves = (size_t)blocks * 4, per_wave = 14000000 / 12 / waves + 1;
+    double gb = (double)waves * per_wave * 12 * 320 / 1e6;   // USEFUL bytes; 384 B (3 lines) are fetched per row
+    char nm[96];
+    snprintf(nm, 96, "random 320B rows cached  %2d waves/CU", wpc); time([&] { gather320<false><<<blocks, 256>>>(p, nrows320, per_wave, out); }, nm, gb);
+    snprintf(nm, 96, "random 320B rows nt      %2d waves/CU", wpc); time([&] { gather320<true><<<blocks, 256>>>(p, nrows320, per_wave, out); }, nm, gb);
   }
   return 0;
 }
