@@ -1488,12 +1488,10 @@ __global__ __launch_bounds__(1024) void exact_select_kernel(u32 L, u32 len, u32 
 // Needs 1024 <= P <= 16384, k <= P, L >= 16; block = P / 16 threads; LDS = P * (sizeof(FT) + 4) + 64 bytes.
 #define ANN_RN_E 16
 __device__ __forceinline__ void rn_cmpx(FT &ka, u32 &ia, FT &kb, u32 &ib) {
-  if (ka > kb) {  // strict: ties and NaN never swap (compute.cl:198-203)
-    const FT t = ka;
-    ka = kb, kb = t;
-    const u32 u = ia;
-    ia = ib, ib = u;
-  }
+  const bool sw = ka > kb;  // strict: ties and NaN never swap (compute.cl:198-203); selects, not a branch
+  const FT lo = sw ? kb : ka, hi = sw ? ka : kb;
+  const u32 il = sw ? ib : ia, ih = sw ? ia : ib;
+  ka = lo, kb = hi, ia = il, ib = ih;
 }
 template <int SS>
 __device__ __forceinline__ void rn_in_regular(FT (&k)[ANN_RN_E], u32 (&id)[ANN_RN_E]) {  // pairs (j, j | 2^SS)
