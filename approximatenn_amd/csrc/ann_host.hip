@@ -75,8 +75,6 @@ struct EnvCfg {
   size_t lds_row_max = 150 * 1024, exact_bytes = (size_t)1 << 30;
   size_t exact_rows = 0;  // ANN_HIP_EXACT_ROWS: rows of the device-driven exact workspace (0 = auto)
   int cache_mode = 0;  // ANN_HIP_CACHE: 0 sampled fingerprint (default), 1 strict (full content hash), 2 off
-  int regnet = 1;       // ANN_HIP_REGNET: 0 = the exact path's literal network always in its LDS form, 1 = register form
-                        // for the few rows of a batch's exact path (default), 2 = register form whenever the shape fits (tests)
   size_t bk_group = 0;  // ANN_HIP_BK_GROUP: cap on the members per pass of precomp's bucket kernel (0 = what fits the LDS)
 };
 static EnvCfg g_env;
@@ -106,7 +104,6 @@ static void load_env() {
   c.exact_bytes = env_size("ANN_HIP_EXACT_BYTES", (size_t)1 << 30);
   c.exact_rows = env_size("ANN_HIP_EXACT_ROWS", 0);
   c.bk_group = env_size("ANN_HIP_BK_GROUP", 0);
-  c.regnet = env_int("ANN_HIP_REGNET", 1);
   const char *cm = getenv("ANN_HIP_CACHE");
   c.cache_mode = !cm ? 0 : !strcmp(cm, "strict") ? 1 : !strcmp(cm, "off") ? 2 : 0;
   g_env = c;
@@ -835,17 +832,6 @@ static void launch_exact_select(u32 L, u32 len, u32 in_stride, int k, size_t nq,
   if (block < 64) block = 64;
   const size_t smem = (size_t)len * (sizeof(FT) + sizeof(u32));
   const unsigned grid = live_rows ? (unsigned)std::min<size_t>(nq, 512) : (unsigned)nq;
-  // a handful of long rows (the flagged queries of a batch): the register form of the same network, ~8x less latency
-  const u32 Pn = 1u << lk;
-  if (env().regnet && L >= 16 && Pn >= 1024 && Pn <= 16384 && (u32)k <= Pn && len >= std::min(L, Pn + 1) &&
-      (live_rows || nq <= 64 || env().regnet == 2) && Pn / ANN_RN_E <= max_block) {
-    const size_t sm = (size_t)Pn * (sizeof(FT) + sizeof(u32)) + 64;
-    allow_lds(exact_select_reg_kernel, sm);
-    hipLaunchKernelGGL(exact_select_reg_kernel, dim3(grid), dim3(Pn / ANN_RN_E), sm, s, L, len, in_stride, k, ids, dist, qidx,
-                       xbase, out_i, out_d, ostride, ooff, live_rows, (u32)nq, out64, live_off);
-    HIPCHECK(hipGetLastError());
-    return;
-  }
   if (smem <= env().lds_row_max) {  // the whole row in LDS (a CU has 160 KB); longer rows sort in place in HBM
     allow_lds(exact_select_kernel<true>, smem);
     hipLaunchKernelGGL(exact_select_kernel<true>, dim3(grid), dim3(block), smem, s, L, len, in_stride, k,

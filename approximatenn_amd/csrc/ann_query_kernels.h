@@ -1477,138 +1477,6 @@ __global__ __launch_bounds__(1024) void exact_select_kernel(u32 L, u32 len, u32 
   }
 }
 
-// ------------------------------------------------------------------------------- exact_select, register form
-// The same compare-exchange sequence as block_sort_net / block_topk_stage (sort_two_step, compute.cl:181-206, driven as
-// alg.c:137-144; rdups compute.cl:212-217), for the LATENCY of a handful of rows: the queries whose selection proof failed
-// (a genuine tie among the k+1 best; ~0.7 per 10k at cfg3, i.e. in most batches) wait for this kernel on the critical
-// path of the step.  Thread t holds entries [16t, 16t+16) of the sorted prefix P = 2^floor(log2 L) in registers:
-// sub-steps with stride < 16 are compare-exchanges between registers, strides 16 .. 512 (partner thread in the same
-// wave) take wave shuffles, and only the strides that cross waves go through LDS (3 of the 78 sub-steps at P = 4096).
-// The LDS form does 78 workgroup-wide passes per sort: 79 us per row at P = 4096 against ~10 us here.
-// Needs 1024 <= P <= 16384, k <= P, L >= 16; block = P / 16 threads; LDS = P * (sizeof(FT) + 4) + 64 bytes.
-#define ANN_RN_E 16
-__device__ __forceinline__ void rn_cmpx(FT &ka, u32 &ia, FT &kb, u32 &ib) {
-  const bool sw = ka > kb;  // strict: ties and NaN never swap (compute.cl:198-203); selects, not a branch
-  const FT lo = sw ? kb : ka, hi = sw ? ka : kb;
-  const u32 il = sw ? ib : ia, ih = sw ? ia : ib;
-  ka = lo, kb = hi, ia = il, ib = ih;
-}
-template <int SS>
-__device__ __forceinline__ void rn_in_regular(FT (&k)[ANN_RN_E], u32 (&id)[ANN_RN_E]) {  // pairs (j, j | 2^SS)
-#pragma unroll
-  for (int j = 0; j < ANN_RN_E; j++)
-    if (!(j & (1 << SS))) rn_cmpx(k[j], id[j], k[j | (1 << SS)], id[j | (1 << SS)]);
-}
-template <int S>
-__device__ __forceinline__ void rn_in_mirror(FT (&k)[ANN_RN_E], u32 (&id)[ANN_RN_E]) {  // ss == s: (base+lo, base+2^(S+1)-1-lo)
-  constexpr int B = 2 << S;
-#pragma unroll
-  for (int j = 0; j < ANN_RN_E; j++)
-    if ((j & (B - 1)) < B / 2) rn_cmpx(k[j], id[j], k[(j & ~(B - 1)) + B - 1 - (j & (B - 1))], id[(j & ~(B - 1)) + B - 1 - (j & (B - 1))]);
-}
-
-// do_sort on the 16 * blockDim.x entries the workgroup holds; lds_k / lds_i: FT[P] / u32[P] (used for cross-wave strides)
-__device__ inline void rn_sort(int lk, FT (&k)[ANN_RN_E], u32 (&id)[ANN_RN_E], FT *lds_k, u32 *lds_i) {
-  const int t = threadIdx.x, T = blockDim.x;
-  for (int s = 0; s < lk; s++)
-    for (int ss = s; ss >= 0; ss--) {
-      const bool mirror = ss == s;
-      if (ss <= 3) {
-        if (mirror) {
-          if (ss == 0) rn_in_mirror<0>(k, id);
-          else if (ss == 1) rn_in_mirror<1>(k, id);
-          else if (ss == 2) rn_in_mirror<2>(k, id);
-          else rn_in_mirror<3>(k, id);
-        } else {
-          if (ss == 0) rn_in_regular<0>(k, id);
-          else if (ss == 1) rn_in_regular<1>(k, id);
-          else if (ss == 2) rn_in_regular<2>(k, id);
-          else rn_in_regular<3>(k, id);
-        }
-        continue;
-      }
-      const int bit = ss - 4;  // the partner thread differs in this bit (regular) / in bits [0, bit] (mirrored block)
-      const int mask = mirror ? (2 << bit) - 1 : 1 << bit;
-      const bool lower = !((t >> bit) & 1);
-      FT ok[ANN_RN_E];
-      u32 oi[ANN_RN_E];
-      if (mask < ANN_WAVE) {
-        if (mirror) {
-#pragma unroll
-          for (int j = 0; j < ANN_RN_E; j++) ok[j] = __shfl_xor(k[ANN_RN_E - 1 - j], mask), oi[j] = __shfl_xor(id[ANN_RN_E - 1 - j], mask);
-        } else {
-#pragma unroll
-          for (int j = 0; j < ANN_RN_E; j++) ok[j] = __shfl_xor(k[j], mask), oi[j] = __shfl_xor(id[j], mask);
-        }
-      } else {  // across waves: entry j of thread t sits at [j * T + t] (conflict-free both ways)
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < ANN_RN_E; j++) lds_k[j * T + t] = k[j], lds_i[j * T + t] = id[j];
-        __syncthreads();
-        const int pt = t ^ mask;
-        if (mirror) {
-#pragma unroll
-          for (int j = 0; j < ANN_RN_E; j++) ok[j] = lds_k[(ANN_RN_E - 1 - j) * T + pt], oi[j] = lds_i[(ANN_RN_E - 1 - j) * T + pt];
-        } else {
-#pragma unroll
-          for (int j = 0; j < ANN_RN_E; j++) ok[j] = lds_k[j * T + pt], oi[j] = lds_i[j * T + pt];
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < ANN_RN_E; j++) {
-        const bool take = lower ? (k[j] > ok[j]) : (ok[j] > k[j]);  // the lower index keeps the smaller key, strictly
-        if (take) k[j] = ok[j], id[j] = oi[j];
-      }
-    }
-}
-
-__global__ __launch_bounds__(1024) void exact_select_reg_kernel(u32 L, u32 len, u32 in_stride, int k,
-                                                               const u32 *__restrict__ ids_in,
-                                                               const FT *__restrict__ dist_in,
-                                                               const u32 *__restrict__ qidx, u32 xbase,
-                                                               u32 *__restrict__ out_id, FT *__restrict__ out_dist,
-                                                               int ostride, int ooff, const u32 *__restrict__ live_rows,
-                                                               u32 nrows, size_t *__restrict__ out64, u32 live_off) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int lk = ann_lg(L), t = threadIdx.x, T = blockDim.x;
-  const u32 P = (u32)T * ANN_RN_E;  // == 1 << lk (checked by the launcher)
-  FT *lds_k = reinterpret_cast<FT *>(smem);
-  u32 *lds_i = reinterpret_cast<u32 *>(lds_k + P);
-  u32 *lds_first = lds_i + P;  // id[0] of lane 0 of every wave (the duplicate test across a wave boundary)
-  if (live_rows) nrows = min(nrows, max(*live_rows, live_off) - live_off);
-  for (u32 row = blockIdx.x; row < nrows; row += gridDim.x) {
-    const u32 x = qidx ? qidx[row] : xbase + row;
-    const u32 *gi = ids_in + (size_t)row * in_stride;
-    const FT *gd = dist_in + (size_t)row * in_stride;
-    FT key[ANN_RN_E];
-    u32 id[ANN_RN_E];
-#pragma unroll
-    for (int j = 0; j < ANN_RN_E; j++) key[j] = gd[t * ANN_RN_E + j], id[j] = gi[t * ANN_RN_E + j];
-    rn_sort(lk, key, id, lds_k, lds_i);
-    // rdups: the first of each adjacent equal-id pair gets +inf; "adjacent" crosses thread, wave and prefix borders
-    __syncthreads();
-    if ((t & (ANN_WAVE - 1)) == 0) lds_first[t >> 6] = id[0];
-    __syncthreads();
-    u32 nxt = __shfl_down(id[0], 1);
-    if ((t & (ANN_WAVE - 1)) == ANN_WAVE - 1) nxt = t + 1 < T ? lds_first[(t >> 6) + 1] : (P < len ? gi[P] : ~id[ANN_RN_E - 1]);
-    const FT inf = ft_inf();
-#pragma unroll
-    for (int j = 0; j < ANN_RN_E; j++)
-      if (id[j] == (j + 1 < ANN_RN_E ? id[j + 1] : nxt)) key[j] = key[j] + inf;
-    rn_sort(lk, key, id, lds_k, lds_i);
-#pragma unroll
-    for (int j = 0; j < ANN_RN_E; j++) {
-      const int o = t * ANN_RN_E + j;
-      if (o < k) {
-        if (out64) out64[(size_t)x * ostride + ooff + o] = id[j];
-        else out_id[(size_t)x * ostride + ooff + o] = id[j];
-        out_dist[(size_t)x * ostride + ooff + o] = key[j];
-      }
-    }
-    __syncthreads();
-  }
-}
-
 // ---------------------------------------------------------------- point-sharded hosts, owner protocol
 // Queries are dealt to OWNER devices in contiguous slices of qs.  After the all-to-all of stage-1 candidates the
 // owner holds, for each of its nq queries, G ascending lists of K1 distinct packed keys (ids disjoint across
