@@ -1572,6 +1572,27 @@ extern "C" void annhip_recall_ranks(size_t n, size_t d, size_t k, const ftype *p
   HIPCHECK(hipFree(hist));
 }
 
+// the same with host pointers in and out (ranks_host: unsigned long long[ycnt*k]) -- for plain-C drivers such as
+// tests/harness/test_correctness.c, the counterpart of /root/reference/test_correctness.c
+extern "C" void annhip_recall_ranks_host(size_t n, size_t d, size_t k, const ftype *points, size_t Q, const ftype *y,
+                                         const size_t *guess, int self, unsigned long long *ranks_host) {
+  RandGuard keep_callers_stream;
+  gpu_init();
+  if (!Q || !k) return;
+  FT *dp = dev_alloc<FT>(n * d), *dy = (y == points) ? dp : dev_alloc<FT>(Q * d);
+  size_t *dg = dev_alloc<size_t>(Q * k);
+  unsigned long long *dr = dev_alloc<unsigned long long>(Q * k);
+  HIPCHECK(hipMemcpy(dp, points, sizeof(FT) * n * d, hipMemcpyHostToDevice));
+  if (dy != dp) HIPCHECK(hipMemcpy(dy, y, sizeof(FT) * Q * d, hipMemcpyHostToDevice));
+  HIPCHECK(hipMemcpy(dg, guess, sizeof(size_t) * Q * k, hipMemcpyHostToDevice));
+  annhip_recall_ranks(n, d, k, reinterpret_cast<const ftype *>(dp), Q, reinterpret_cast<const ftype *>(dy), dg, self, dr);
+  HIPCHECK(hipMemcpy(ranks_host, dr, sizeof(unsigned long long) * Q * k, hipMemcpyDeviceToHost));
+  HIPCHECK(hipFree(dp));
+  if (dy != dp) HIPCHECK(hipFree(dy));
+  HIPCHECK(hipFree(dg));
+  HIPCHECK(hipFree(dr));
+}
+
 // ----------------------------------------------------------------------------- precomp
 // rand_pr.c:8: uniform [0,1) from libc random()
 static double unit_draw(void) { return (double)(unsigned long)random() / ((double)RAND_MAX + 1); }

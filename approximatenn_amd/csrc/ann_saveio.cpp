@@ -12,6 +12,8 @@
 //   id    which_par[t][2^d_short * par_maxes[t]]   for t = 0..tries-1
 //   u64   checksum of everything above (four interleaved 64-bit multiply lanes over 8-byte words: ~5 GB/s on one
 //         core, where the byte-wise FNV of format 1 managed ~0.7 GB/s on the 2-3 GB of a cfg3 index)
+// Format 1 ("ANNSAVE1", written by the first round of this backend) is the same layout with an FNV-1a-64 checksum;
+// it is still READ (behind the same size, checksum and id-range checks); files are always written as format 2.
 // Reading checks the header against the FILE SIZE before it allocates anything, verifies the checksum, then checks
 // every id against its range (which_par <= n, graph below the sentinel bound) -- a file that passes cannot make a kernel gather out of
 // bounds.  It returns malloc'd fields exactly as precomp() fills them (free_save() releases them).
@@ -87,15 +89,30 @@ struct Writer {
   }
 };
 
+struct Fnv1a {  // the checksum of format 1
+  uint64_t h = 1469598103934665603ull;
+  void feed(const void *p, size_t nbytes) {
+    const unsigned char *b = (const unsigned char *)p;
+    for (size_t i = 0; i < nbytes; i++) h = (h ^ b[i]) * 1099511628211ull;
+  }
+};
+
 struct Reader {
   FILE *f;
   Hasher hs;
+  Fnv1a old;
+  int version = 2;  // set from the magic before anything is fed
   bool ok = true;
   void get(void *p, size_t nbytes) {
     if (!ok) return;
     ok = fread(p, 1, nbytes, f) == nbytes;
-    if (ok) hs.feed(p, nbytes);
+    if (ok) feed(p, nbytes);
   }
+  void feed(const void *p, size_t nbytes) {
+    if (version == 1) old.feed(p, nbytes);
+    else hs.feed(p, nbytes);
+  }
+  uint64_t sum() { return version == 1 ? old.h : hs.done(); }
   // ids of one section, widened to size_t; *max_id = the largest id seen
   size_t *get_ids(size_t count, unsigned id_bytes, size_t *max_id) {
     size_t *out = (size_t *)malloc(sizeof(size_t) * (count ? count : 1));
@@ -182,11 +199,14 @@ extern "C" int annhip_save_read(const char *path, save_t *save) {
   char magic[8];
   uint32_t fb = 0, ib = 0;
   uint64_t dims[5] = {0, 0, 0, 0, 0};
-  r.get(magic, 8);
+  if (fread(magic, 1, 8, f) != 8 || (memcmp(magic, "ANNSAVE2", 8) && memcmp(magic, "ANNSAVE1", 8)))
+    return fclose(f), fail("not an index file of this library (magic ANNSAVE2, or ANNSAVE1 of its first format)", path);
+  r.version = magic[7] == '1' ? 1 : 2;
+  r.feed(magic, 8);
   r.get(&fb, 4);
   r.get(&ib, 4);
   r.get(dims, sizeof dims);
-  if (!r.ok || memcmp(magic, "ANNSAVE2", 8)) return fclose(f), fail("not an ANNSAVE2 index file", path);
+  if (!r.ok) return fclose(f), fail("truncated index file (header)", path);
   if (fb != sizeof(ftype)) return fclose(f), fail("index file was written by the other precision build (ftype.h)", path);
   const size_t T = dims[0], n = dims[1], k = dims[2], ds = dims[3], d = dims[4];
   if ((ib != 4 && ib != 8) || T == 0 || T > 4096 || ds > 40 || k == 0 || n <= k || d == 0 || d > ((size_t)1 << 24) ||
@@ -227,7 +247,7 @@ extern "C" int annhip_save_read(const char *path, save_t *save) {
     save->which_par[t] = r.get_ids(save->par_maxes[t] << ds, ib, &mx);
     max_tab = mx > max_tab ? mx : max_tab;
   }
-  const uint64_t want = r.hs.done();
+  const uint64_t want = r.sum();
   uint64_t got = 0;
   const bool sum_ok = r.ok && fread(&got, 1, 8, f) == 8 && got == want;
   fclose(f);

@@ -247,6 +247,9 @@ unsigned long long annhip_index_checksum(annhip_index *ix);
  * graph precomp returns).  Synchronous. */
 void annhip_recall_ranks(size_t n, size_t d, size_t k, const ftype *points_dev, size_t ycnt, const ftype *y_dev,
                          const size_t *guess_dev, int self, unsigned long long *ranks_dev);
+/* The same with HOST pointers in and out (uploads, scores, downloads): for plain-C drivers (tests/harness/test_correctness.c). */
+void annhip_recall_ranks_host(size_t n, size_t d, size_t k, const ftype *points, size_t ycnt, const ftype *y,
+                              const size_t *guess, int self, unsigned long long *ranks_host);
 
 /* ---- synthetic data of the reference's drivers ------------------------------------------------------ */
 /* out[0..count) = iid N(0,1) by Box-Muller on the CALLER's libc random() stream, value for value what genRand /

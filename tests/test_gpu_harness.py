@@ -41,3 +41,19 @@ def test_compare_results_many_seeds(prec):
     for seed in range(100, 130):
         out = _run([os.path.join(H, "compare_results_" + prec), "-o", "1", "-S", str(seed)])
         assert "Average diffs for comp: 0\n" in out and "PASS" in out and "0 not bit-identical" in out, (seed, out)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_test_correctness_tool_gpu_and_cpu_columns_agree(prec):
+    """tests/harness/test_correctness (counterpart of the reference's recall driver, test_correctness.c:92-141): the three
+    quality numbers for precomp's graph and for query batches; the GPU column and the CPU column (-c: the oracle's
+    answers, same scorer) must print the same numbers, the answers being bit-identical."""
+    import re
+    exe = os.path.join(H, "test_correctness_" + prec)
+    for args in (["-o", "2", "-S", "5"], ["-n", "4000", "-d", "64", "-y", "300", "-o", "2", "-S", "6"]):
+        g = _run([exe] + args)
+        c = _run([exe] + args + ["-c"])
+        num = lambda txt: [float(v.rstrip(".")) for v in re.findall(r": ([0-9.e+-]+)", txt)]  # noqa: E731
+        assert "Average index score for" in g and "Prob correct" in g and "Max index score" in g
+        assert "(on GPU)" in g and "(on CPU)" in c and num(g) == num(c), (g, c)
+        assert 0.0 < num(g)[1] <= 1.0

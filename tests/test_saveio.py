@@ -114,3 +114,29 @@ def test_checksum_throughput(tmp_path):
         back.free()
     mb = os.path.getsize(path) / 1e6
     assert mb / (t1 - t0) > 100 and mb / (t2 - t1) > 100, (mb, t1 - t0, t2 - t1)   # MB/s, generous lower bound
+
+
+def test_format_1_files_are_still_read(tmp_path):
+    """Index files of the library's first format (magic ANNSAVE1, FNV-1a-64 checksum over the same layout) load like
+    format 2 -- behind the same size, checksum and id-range checks."""
+    g = load_golden("tiny_appendixA_f32")
+    save = A.Save.from_dict("f32", g["save"])
+    path = tmp_path / "index2.ann"
+    save.write(path)
+    body = bytearray(open(path, "rb").read()[:-8])
+    body[:8] = b"ANNSAVE1"
+    h = 1469598103934665603
+    for b in body:                                   # FNV-1a, 64 bit
+        h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    old = tmp_path / "index1.ann"
+    old.write_bytes(bytes(body) + h.to_bytes(8, "little"))
+    back = A.Save.read("f32", old)
+    try:
+        assert_save_equal(back.to_dict(), g["save"])
+    finally:
+        back.free()
+    bad = bytearray(old.read_bytes())
+    bad[200] ^= 1                                    # a flipped bit: the old checksum catches it too
+    (tmp_path / "bad1.ann").write_bytes(bytes(bad))
+    with pytest.raises(OSError):
+        A.Save.read("f32", tmp_path / "bad1.ann")

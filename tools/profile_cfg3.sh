@@ -14,6 +14,6 @@ echo "FETCH_SIZE done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_w -- python3 $args > gpurun_out/prof_w.log 2>&1
 echo "WRITE_SIZE done"
 python3 tools/summarize_profile.py $(find gpurun_out/prof_kt -name "*kernel_trace.csv") $(find gpurun_out/prof_f -name "*counter_collection.csv") \
-   $(find gpurun_out/prof_w -name "*counter_collection.csv") 2560000 $out "round 2 (final build): $args (cfg3 N=10M d=128 k=10 Q=10k f32, reference-stream data), MI355X"
+   $(find gpurun_out/prof_w -name "*counter_collection.csv") 2560000 $out "round 3: $args (cfg3 N=10M d=128 k=10 Q=10k f32, reference-stream data), MI355X"
 grep "^{" gpurun_out/prof_kt.log > gpurun_out/prof_kt_bench.json
 rm -rf gpurun_out/prof_kt gpurun_out/prof_f gpurun_out/prof_w
