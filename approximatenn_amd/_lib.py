@@ -115,6 +115,7 @@ def load(prec="f32"):
     lib.annhip_stage1_rows.argtypes = [vp, sz, vp, C.c_int, u32p, u32p, sz, u32p, vp]
     lib.annhip_stage2_rows_list.argtypes = [vp, sz, vp, C.c_int, u32p, sz, u32p, vp, u32p, vp]
     lib.annhip_exact_select.argtypes = [vp, C.c_int, sz, u32p, vp, u32p, u32p, vp]
+    lib.annhip_test_sort_rows.argtypes = [sz, sz, sz, u32p, vp, vp, u32p, u32p, vp, vp]
     lib.annhip_recall_ranks.argtypes = [sz, sz, sz, vp, sz, vp, vp, C.c_int, vp]
     lib.annhip_recall_ranks_host.argtypes = [sz, sz, sz, vp, sz, vp, vp, C.c_int, vp]
     lib.annhip_checksum_dev.restype = C.c_ulonglong
@@ -158,7 +159,7 @@ EXPORTED = ["gpu_init", "gpu_cleanup", "register_cleanup", "query_gpu", "precomp
             "annhip_index_export", "annhip_index_reshard", "annhip_save_write", "annhip_save_read", "annhip_precomp_index", "annhip_precomp_begin", "annhip_precomp_info", "annhip_precomp_init_merged", "annhip_precomp_hash",
             "annhip_precomp_try", "annhip_precomp_merge", "annhip_precomp_graph", "annhip_precomp_finish", "annhip_query", "annhip_workspace_create", "annhip_workspace_destroy", "annhip_query_on", "annhip_query_slice", "annhip_stream_open", "annhip_stream_submit", "annhip_stream_collect", "annhip_stream_close",
             "annhip_key_bytes", "annhip_stream_create_reserving", "annhip_stream_destroy", "annhip_sh_codes", "annhip_sh_stage1", "annhip_sh_merge_finalize", "annhip_sh_exact1_begin", "annhip_sh_exact1_end", "annhip_sh_stage2",
-            "annhip_sh_final", "annhip_stage1_rows", "annhip_stage2_rows_list", "annhip_exact_select",
+            "annhip_sh_final", "annhip_stage1_rows", "annhip_stage2_rows_list", "annhip_exact_select", "annhip_test_sort_rows",
             "annhip_recall_ranks", "annhip_recall_ranks_host", "annhip_checksum_dev", "annhip_index_checksum", "annhip_profile", "annhip_stats", "annhip_stage_ms",
             "annhip_cache_clear", "annhip_fingerprint_ms", "annhip_cache_drop", "annhip_cache_size", "annhip_reload_env",
             "annhip_synth_randnorm", "annhip_synth_reset", "annhip_host_profile", "annhip_host_stats",

@@ -348,7 +348,7 @@ class Index:
         out = (C.c_double * 8)()
         self.lib.annhip_stats(self.h, C.byref(out), int(reset))
         return dict(s1_launches=out[0], s1_ms=out[1], s1_rows=out[2], other_rows=out[3], exact_queries=out[4],
-                    queries=out[5])
+                    queries=out[5], tie_queries=out[6])  # tie_queries: flagged queries answered without the network (ann_tie.h)
 
     def stage_ms(self):
         out = (C.c_double * 6)()

@@ -40,6 +40,15 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ u32 mask_rank(u64 m) {
   return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0));
 }
+// inclusive prefix sum over the lanes of a wave
+__device__ __forceinline__ u32 wave_incl_scan(u32 v) {
+#pragma unroll
+  for (int o = 1; o < ANN_WAVE; o <<= 1) {
+    u32 t = __shfl_up(v, o);
+    if (lane_id() >= o) v += t;
+  }
+  return v;
+}
 // LDS traffic between lanes of ONE wave: DS ops of a wave execute in order, so a wave-scope
 // fence (compiler + memory ordering) is all that is needed.
 __device__ __forceinline__ void wave_lds_sync() {

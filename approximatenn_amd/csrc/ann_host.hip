@@ -76,6 +76,7 @@ struct EnvCfg {
   size_t exact_rows = 0;  // ANN_HIP_EXACT_ROWS: rows of the device-driven exact workspace (0 = auto)
   int cache_mode = 0;  // ANN_HIP_CACHE: 0 sampled fingerprint (default), 1 strict (full content hash), 2 off
   size_t bk_group = 0;  // ANN_HIP_BK_GROUP: cap on the members per pass of precomp's bucket kernel (0 = what fits the LDS)
+  int tie = 1;          // ANN_HIP_TIE: 0 = flagged rows always take the literal network (no tie path, ann_tie.h)
 };
 static EnvCfg g_env;
 static size_t env_size(const char *name, size_t dflt) {
@@ -104,6 +105,7 @@ static void load_env() {
   c.exact_bytes = env_size("ANN_HIP_EXACT_BYTES", (size_t)1 << 30);
   c.exact_rows = env_size("ANN_HIP_EXACT_ROWS", 0);
   c.bk_group = env_size("ANN_HIP_BK_GROUP", 0);
+  c.tie = env_int("ANN_HIP_TIE", 1);
   const char *cm = getenv("ANN_HIP_CACHE");
   c.cache_mode = !cm ? 0 : !strcmp(cm, "strict") ? 1 : !strcmp(cm, "off") ? 2 : 0;
   g_env = c;
@@ -272,7 +274,7 @@ struct annhip_index {
   annhip_workspace ws;           // default workspace (annhip_query, staged calls)
   DevBuf io_y, io_ids, io_dist;  // query_gpu's staging of host inputs/outputs, reused between calls
   PinBuf io_y_pin, io_out_pin;   // ... and their pinned host-side bounce buffers
-  unsigned long long *d_rows = NULL;  // [0] stage-1 gathered rows, [2] exact-path queries, [8..8+512) rows kernels (64 padded shards)
+  unsigned long long *d_rows = NULL;  // [0] stage-1 gathered rows, [2] exact-path queries, [3] of those: answered by the tie path, [8..8+512) rows kernels (64 padded shards)
   // measurement
   bool profile = false;
   std::vector<EventPair> ev_used, ev_free;
@@ -817,11 +819,13 @@ static void launch_rows(const QParams &P, size_t Q, const FT *y, int alias, cons
   HIPCHECK(hipGetLastError());
 }
 
-// network + rdups + network on nq rows of reference length L, `len` stored entries, row stride in_stride
+// network + rdups + network on nq rows of reference length L, `len` stored entries, row stride in_stride.
+// tie: stage 1's candidate lists of the rows' queries -- rows with one run of tied distances are answered from their
+// class bits by wave 0 (ann_tie.h), the others by the network (ANN_HIP_TIE=0: always the network).
 static void launch_exact_select(u32 L, u32 len, u32 in_stride, int k, size_t nq, u32 *ids, FT *dist,
                                 const u32 *qidx, u32 xbase, u32 *out_i, FT *out_d, int ostride, int ooff,
                                 hipStream_t s, const u32 *live_rows = NULL, size_t *out64 = NULL, unsigned max_block = 1024,
-                                u32 live_off = 0) {
+                                u32 live_off = 0, TieArgs tie = TieArgs{NULL, NULL, 0, NULL}) {
   if (!nq) return;
   const int lk = ann_lg(L);
   unsigned npairs = 8u << (lk > 4 ? lk - 4 : 0);
@@ -830,15 +834,32 @@ static void launch_exact_select(u32 L, u32 len, u32 in_stride, int k, size_t nq,
   // alone, 1.1 ms = until the gather drained, next to the sharded stage 1): launches that run beside gathers use 256.
   unsigned block = npairs >= max_block ? max_block : ((npairs + 63) / 64) * 64;
   if (block < 64) block = 64;
-  const size_t smem = (size_t)len * (sizeof(FT) + sizeof(u32));
+  const size_t row_smem = (size_t)len * (sizeof(FT) + sizeof(u32));
   const unsigned grid = live_rows ? (unsigned)std::min<size_t>(nq, 512) : (unsigned)nq;
-  if (smem <= env().lds_row_max) {  // the whole row in LDS (a CU has 160 KB); longer rows sort in place in HBM
-    allow_lds(exact_select_kernel<true>, smem);
-    hipLaunchKernelGGL(exact_select_kernel<true>, dim3(grid), dim3(block), smem, s, L, len, in_stride, k,
-                       ids, dist, qidx, xbase, out_i, out_d, ostride, ooff, live_rows, (u32)nq, out64, live_off);
-  } else
-    hipLaunchKernelGGL(exact_select_kernel<false>, dim3(grid), dim3(block), 0, s, L, len, in_stride, k,
-                       ids, dist, qidx, xbase, out_i, out_d, ostride, ooff, live_rows, (u32)nq, out64, live_off);
+  const bool in_lds = row_smem <= env().lds_row_max;  // the whole row in LDS (a CU has 160 KB); longer rows sort in place in HBM
+  const u32 Pn = (u32)1 << lk;
+  int nw = 0;
+  if (tie.cand_d && env().tie && L >= 16 && tie.K1 == k + 1 && tie.K1 <= ANN_WAVE && (u32)k <= Pn)
+    nw = Pn <= 4096 ? 1 : Pn <= 8192 ? 2 : Pn <= 16384 ? 4 : 0;
+  if (!nw) tie = TieArgs{NULL, NULL, 0, NULL};
+  const size_t smem = std::max(in_lds ? row_smem : (size_t)0, nw ? ann_tie_lds_bytes(nw) : (size_t)0);
+#define CALL(LDS, NW)                                                                                                  \
+  do {                                                                                                                 \
+    allow_lds((exact_select_kernel<LDS, NW>), smem);                                                                   \
+    hipLaunchKernelGGL((exact_select_kernel<LDS, NW>), dim3(grid), dim3(block), smem, s, L, len, in_stride, k, ids,    \
+                       dist, qidx, xbase, out_i, out_d, ostride, ooff, live_rows, (u32)nq, out64, live_off, tie);      \
+  } while (0)
+#define CALL_NW(LDS)             \
+  do {                           \
+    if (nw == 0) CALL(LDS, 0);   \
+    else if (nw == 1) CALL(LDS, 1); \
+    else if (nw == 2) CALL(LDS, 2); \
+    else CALL(LDS, 4);           \
+  } while (0)
+  if (in_lds) CALL_NW(true);
+  else CALL_NW(false);
+#undef CALL_NW
+#undef CALL
   HIPCHECK(hipGetLastError());
 }
 
@@ -946,7 +967,7 @@ static long finalize_and_fallback(annhip_index *ix, const QParams &P, size_t Q, 
         launch_rows<MODE_TABLE>(P, Q, y, alias, codes, fl + p0, 0, nq, P.Lc1, NULL, NULL, ids, dist, rows_done, s, d_fcount,
                                 (u32)p0, qstride);
         launch_exact_select(P.L1, P.Lc1, P.Lc1, P.k, nq, ids, dist, fl + p0, 0, top_i, top_d, ostride, ooff, s, d_fcount,
-                            NULL, 1024, (u32)p0);
+                            NULL, 1024, (u32)p0, TieArgs{cand_d, cand_i, K1, ix ? ix->d_rows + 3 : NULL});
       }
       return -1;
     }
@@ -969,7 +990,8 @@ static long finalize_and_fallback(annhip_index *ix, const QParams &P, size_t Q, 
     FT *dist = (FT *)xd.need(sizeof(FT) * nq * P.Lc1);
     const u32 *qidx = mode == 0 ? fl + q0 : NULL;
     launch_rows<MODE_TABLE>(P, Q, y, alias, codes, qidx, (u32)q0, nq, P.Lc1, NULL, NULL, ids, dist, rows_done, s, NULL, 0, qstride);
-    launch_exact_select(P.L1, P.Lc1, P.Lc1, P.k, nq, ids, dist, qidx, (u32)q0, top_i, top_d, ostride, ooff, s);
+    launch_exact_select(P.L1, P.Lc1, P.Lc1, P.k, nq, ids, dist, qidx, (u32)q0, top_i, top_d, ostride, ooff, s, NULL, NULL, 1024,
+                        0, mode == 0 ? TieArgs{cand_d, cand_i, K1, ix ? ix->d_rows + 3 : NULL} : TieArgs{NULL, NULL, 0, NULL});
   }
   return (long)nflag;
 }
@@ -1067,14 +1089,17 @@ static long query_impl(annhip_index *ix, annhip_workspace &ws, hipStream_t s, si
       u32 *nvo = (u32 *)ws.nvo.need(sizeof(u32) * Q);
       zero_u32_kernel<<<1, 1, 0, s>>>(ws.d_fcount);
       FusedTail F{1, P.Lc2, ids_dev, out_d, fl, ws.d_fcount, ix->d_rows + 2};
-      launch_stage1(ix, P, Q, y, alias, codes, NULL, NULL, NULL, nvo, s, ix->h_tries, ix->use_seg, F);
+      cand_d = (FT *)ws.cand_d.need(sizeof(FT) * Q * K1);  // written for rejected queries only
+      cand_i = (u32 *)ws.cand_i.need(sizeof(u32) * Q * K1);
+      launch_stage1(ix, P, Q, y, alias, codes, cand_d, cand_i, NULL, nvo, s, ix->h_tries, ix->use_seg, F);
       seg_mark(ix, marks, s);
       // rejected queries (device-side count, normally zero): exact stage 1, then the classic stage 2, for them only
       unsigned long long *rows_ctr = ix->profile ? ix->d_rows + 8 : NULL;
       u32 *xi = (u32 *)ws.xids.need(sizeof(u32) * Q * P.Lc1);
       FT *xd = (FT *)ws.xd.need(sizeof(FT) * Q * P.Lc1);
       launch_rows<MODE_TABLE>(P, Q, y, alias, codes, fl, 0, Q, P.Lc1, NULL, NULL, xi, xd, rows_ctr, s, ws.d_fcount);
-      launch_exact_select(P.L1, P.Lc1, P.Lc1, k, Q, xi, xd, fl, 0, top_i, top_d, k, 0, s, ws.d_fcount);
+      launch_exact_select(P.L1, P.Lc1, P.Lc1, k, Q, xi, xd, fl, 0, top_i, top_d, k, 0, s, ws.d_fcount, NULL, 1024, 0,
+                          TieArgs{cand_d, cand_i, K1, ix->d_rows + 3});
       seg_mark(ix, marks, s);
       u32 *r2i = (u32 *)ws.r2i.need(sizeof(u32) * Q * P.Lc2);
       FT *r2d = (FT *)ws.r2d.need(sizeof(FT) * Q * P.Lc2);
@@ -1275,6 +1300,19 @@ extern "C" void annhip_exact_select(annhip_index *ix, int stage, size_t nq, uint
   const u32 L = stage == 1 ? ix->L1 : ix->L2, len = stage == 1 ? ix->Lc1 : ix->Lc2;
   launch_exact_select(L, len, len, (int)ix->k, nq, ids_dev, reinterpret_cast<FT *>(dist_dev), qidx_dev, 0,
                       out_id_dev, reinterpret_cast<FT *>(out_dist_dev), (int)ix->k, 0, ix->stream);
+}
+
+// Test hook: sort_and_uniq on nq free-standing rows of reference length L (stride len = ann_need_len(L, k)), optionally
+// with the tie path fed by the candidate lists cand_*_dev [nq][k+1]; *resolved_dev counts the rows it answered.
+extern "C" void annhip_test_sort_rows(size_t L, size_t k, size_t nq, uint32_t *ids_dev, ftype *dist_dev,
+                                      const ftype *cand_d_dev, const uint32_t *cand_i_dev, uint32_t *out_id_dev,
+                                      ftype *out_dist_dev, unsigned long long *resolved_dev) {
+  gpu_init();
+  const u32 len = (u32)ann_need_len(L, k);
+  launch_exact_select((u32)L, len, len, (int)k, nq, ids_dev, reinterpret_cast<FT *>(dist_dev), NULL, 0, out_id_dev,
+                      reinterpret_cast<FT *>(out_dist_dev), (int)k, 0, NULL, NULL, NULL, 1024, 0,
+                      TieArgs{reinterpret_cast<const FT *>(cand_d_dev), cand_i_dev, (int)k + 1, resolved_dev});
+  HIPCHECK(hipStreamSynchronize(NULL));
 }
 
 // A HIP stream whose kernels may use every compute unit except `reserve` of them (the highest-numbered ones).
@@ -1504,7 +1542,7 @@ extern "C" void annhip_stats(annhip_index *ix, double out[8], int reset) {
   unsigned long long other = 0;
   for (int i = 0; i < 64; i++) other += rows[8 + i * 8];
   out[0] = ix->s1_launches, out[1] = ix->s1_ms, out[2] = (double)rows[0], out[3] = (double)other;
-  out[4] = (double)rows[2], out[5] = ix->queries, out[6] = out[7] = 0;
+  out[4] = (double)rows[2], out[5] = ix->queries, out[6] = (double)rows[3] /* answered by the tie path */, out[7] = 0;
   if (reset) {
     ix->s1_launches = ix->s1_ms = ix->queries = 0;
     for (double &v : ix->seg_ms) v = 0;

@@ -21,6 +21,7 @@
 // Only slots below ann_need_len() are ever produced.
 #pragma once
 #include "ann_device.h"
+#include "ann_tie.h"
 
 struct TryInfo {   // one try (= one random projection) of the index
   const u32 *tab;  // [2^ds][pm] bucket table, ids descending then padding n  (alg.c:261-266)
@@ -260,15 +261,6 @@ __global__ void build_segx_kernel(size_t nbuckets, u32 pm, const u32 *__restrict
   for (int j = 0; j < ANN_SEGX_INLINE; j++) w[1 + j] = (u32)j < co ? row[j] : ANN_ID_NONE;
   segx[2 * b] = make_uint4(w[0], w[1], w[2], w[3]);
   segx[2 * b + 1] = make_uint4(w[4], w[5], w[6], w[7]);
-}
-
-__device__ __forceinline__ u32 wave_incl_scan(u32 v) {
-#pragma unroll
-  for (int o = 1; o < ANN_WAVE; o <<= 1) {
-    u32 t = __shfl_up(v, o);
-    if (lane_id() >= o) v += t;
-  }
-  return v;
 }
 
 // Per-wave state of the running selection of the k+1 smallest distinct keys.
@@ -1054,6 +1046,11 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
       if (m >= k && !(key_dist(S.kout[k - 1]) < ft_inf())) bad = true;
       if (P.L1 > P.P1 && cnts[0] >= P.P1) bad = true;
       const bool reject = __ballot(bad) != 0;
+      if (reject && cand_dist)  // the exact path's tie shortcut (ann_tie.h) wants the candidate list of a rejected query
+        for (int i = lane; i < K1; i += ANN_WAVE) {
+          cand_dist[(size_t)x * K1 + i] = i < m ? key_dist(S.kout[i]) : ft_inf();
+          cand_id[(size_t)x * K1 + i] = i < m ? key_id(S.kout[i]) : ANN_ID_NONE;
+        }
       if (lane == 0) {
         cnts[3] = reject ? 1u : 0u;
         if (reject) {
@@ -1439,7 +1436,16 @@ __global__ __launch_bounds__(256) void row_dists_kernel(QParams P, int Q, const 
 // sort_and_uniq (alg.c:224-230) on `len` stored entries of a row of reference length L, then the first k
 // entries out.  One workgroup per row.  USE_LDS: the row is staged in LDS, otherwise the network runs in
 // place in global memory (rows too long for LDS; the workgroup owns the row).
-template <bool USE_LDS>
+// Tie path (ann_tie.h): when stage 1's candidate list of the row's query is given, wave 0 first tries to derive the
+// result from the class bits of the row; only rows it cannot take run the network.  NW = 64-bit words per lane
+// (P <= 4096 * NW), 0 = no tie path in this instantiation.
+struct TieArgs {
+  const FT *cand_d;   // [Q][K1] ascending distinct keys of stage 1 (NULL: no tie path)
+  const u32 *cand_i;
+  int K1;
+  unsigned long long *resolved;  // statistics: rows answered by the tie path
+};
+template <bool USE_LDS, int NW>
 __global__ __launch_bounds__(1024) void exact_select_kernel(u32 L, u32 len, u32 in_stride, int k,
                                                            u32 *__restrict__ ids_in,
                                                            FT *__restrict__ dist_in,
@@ -1447,13 +1453,31 @@ __global__ __launch_bounds__(1024) void exact_select_kernel(u32 L, u32 len, u32 
                                                            u32 *__restrict__ out_id,
                                                            FT *__restrict__ out_dist, int ostride,
                                                            int ooff, const u32 *__restrict__ live_rows,
-                                                           u32 nrows, size_t *__restrict__ out64, u32 live_off) {
+                                                           u32 nrows, size_t *__restrict__ out64, u32 live_off, TieArgs T) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int tie_ok;
   if (live_rows) nrows = min(nrows, max(*live_rows, live_off) - live_off);  // persistent grid over the device-side row count
   for (u32 row = blockIdx.x; row < nrows; row += gridDim.x) {
   const u32 x = qidx ? qidx[row] : xbase + row;
   u32 *gi = ids_in + (size_t)row * in_stride;
   FT *gd = dist_in + (size_t)row * in_stride;
+  if constexpr (NW > 0) {
+    if (T.cand_d) {  // workgroup-uniform
+      if (threadIdx.x < ANN_WAVE) {
+        const size_t o = (size_t)x * ostride + ooff;
+        const bool ok = tie_resolve<NW>(L, k, T.K1, gi, gd, T.cand_d + (size_t)x * T.K1, T.cand_i + (size_t)x * T.K1, smem,
+                                        out64 ? NULL : out_id + o, out64 ? out64 + o : NULL, out_dist + o);
+        if (threadIdx.x == 0) {
+          tie_ok = ok ? 1 : 0;
+          if (ok && T.resolved) atomicAdd(T.resolved, 1ull);
+        }
+      }
+      __syncthreads();
+      const bool done = tie_ok != 0;
+      __syncthreads();  // tie_ok and the LDS are re-used
+      if (done) continue;
+    }
+  }
   if (USE_LDS) {
     FT *sd = reinterpret_cast<FT *>(smem);
     u32 *si = reinterpret_cast<u32 *>(sd + len);
