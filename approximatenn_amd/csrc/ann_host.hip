@@ -76,6 +76,7 @@ struct EnvCfg {
   size_t exact_rows = 0;  // ANN_HIP_EXACT_ROWS: rows of the device-driven exact workspace (0 = auto)
   int cache_mode = 0;  // ANN_HIP_CACHE: 0 sampled fingerprint (default), 1 strict (full content hash), 2 off
   size_t bk_group = 0;  // ANN_HIP_BK_GROUP: cap on the members per pass of precomp's bucket kernel (0 = what fits the LDS)
+  int fin_tail = 1;     // ANN_HIP_FIN_TAIL: 0 = finalize1 as its own launch after stage 1 (A/B; default: in the stage-1 workgroups' tail)
   int tie = 1;          // ANN_HIP_TIE: 0 = flagged rows always take the literal network (no tie path, ann_tie.h)
 };
 static EnvCfg g_env;
@@ -106,6 +107,7 @@ static void load_env() {
   c.exact_rows = env_size("ANN_HIP_EXACT_ROWS", 0);
   c.bk_group = env_size("ANN_HIP_BK_GROUP", 0);
   c.tie = env_int("ANN_HIP_TIE", 1);
+  c.fin_tail = env_int("ANN_HIP_FIN_TAIL", 1);
   const char *cm = getenv("ANN_HIP_CACHE");
   c.cache_mode = !cm ? 0 : !strcmp(cm, "strict") ? 1 : !strcmp(cm, "off") ? 2 : 0;
   g_env = c;
@@ -602,7 +604,7 @@ static void allow_lds(K kernel, size_t bytes) {
 
 // Qhash <= Q: only the first Qhash queries are hashed.  Stage 1 reads code[i*Q + x] for the tries i that own a
 // slot below Lc1, i.e. flat indices below tries_used*Q, i.e. queries below ceil(tries_used*Q/T).
-static void launch_codes(const QParams &P, size_t Qhash, const FT *y, u32 *codes, hipStream_t s) {
+static void launch_codes(const QParams &P, size_t Qhash, const FT *y, u32 *codes, hipStream_t s, u32 *zero_me = NULL) {
   const int wpb = 4;
   const size_t Q = Qhash;
   const size_t items = Q * (size_t)P.T;
@@ -614,7 +616,7 @@ static void launch_codes(const QParams &P, size_t Qhash, const FT *y, u32 *codes
   do {                                                                                                \
     if (DD > 0) {                                                                                     \
       allow_lds(codes_kernel<DD>, smem);                                                              \
-      hipLaunchKernelGGL(codes_kernel<DD>, grid, dim3(64 * wpb), smem, s, P, (int)Q, y, codes);       \
+      hipLaunchKernelGGL(codes_kernel<DD>, grid, dim3(64 * wpb), smem, s, P, (int)Q, y, codes, zero_me);       \
     }                                                                                                 \
   } while (0)
     ANN_DISPATCH_D(P.d, CALL);
@@ -626,7 +628,7 @@ static void launch_codes(const QParams &P, size_t Qhash, const FT *y, u32 *codes
   do {                                                                                                \
     if (DD <= 0) {                                                                                    \
       allow_lds(codes_kernel<(DD <= 0 ? DD : 0)>, smem);                                              \
-      hipLaunchKernelGGL(codes_kernel<(DD <= 0 ? DD : 0)>, dim3(grid), dim3(64 * wpb), smem, s, P, (int)Q, y, codes); \
+      hipLaunchKernelGGL(codes_kernel<(DD <= 0 ? DD : 0)>, dim3(grid), dim3(64 * wpb), smem, s, P, (int)Q, y, codes, zero_me); \
     }                                                                                                 \
   } while (0)
     ANN_DISPATCH_D(P.d, CALL);
@@ -678,14 +680,14 @@ __global__ void sum_u32_kernel(size_t count, const u32 *__restrict__ v, unsigned
 
 static void launch_stage1(annhip_index *ix, const QParams &P, size_t Q, const FT *y, int alias,
                           const u32 *codes, FT *cand_d, u32 *cand_i, u32 *nvt, u32 *nvo, hipStream_t s,
-                          const std::vector<TryInfo> &h_tries, int use_seg, FusedTail F = FusedTail{0, 0, NULL, NULL, NULL, NULL, NULL},
+                          const std::vector<TryInfo> &h_tries, int use_seg, FusedTail F = FusedTail{0, 0, NULL, NULL, NULL, NULL, NULL, NULL, NULL},
                           Key *cand_key = NULL, int pieces = 1, int slots = 0, size_t qstride = 0) {
   // qstride: stride of the try-major code array the kernel reads as codes[try * qstride + x] (0 = Q; a host that answers
   // a SLICE of a larger batch passes the whole batch's size and a code pointer offset to the slice, annhip_query_slice)
   const int kq = (int)(qstride ? qstride : Q);
   if (!Q) return;
   const int K1 = P.k + 1, W = stage1_waves(P.P1, (double)(P.hi - P.lo) / (double)P.n), cap = stage1_cap(W, K1);
-  const size_t smem = stage1_lds_bytes(P, W, K1, cap, F.enabled ? F.len2 : 0);
+  const size_t smem = stage1_lds_bytes(P, W, K1, cap, F.enabled == 1 ? F.len2 : 0);
   u32 runs_used = 0;  // (try, hamming neighbour) runs that start below P1, in slot order
   for (int t = 0; t < P.T; t++)
     for (int yy = 0; yy <= P.ds; yy++)
@@ -725,9 +727,9 @@ static void launch_stage1(annhip_index *ix, const QParams &P, size_t Q, const FT
 #define CALL(DD)                                 \
   do {                                           \
     if (use_seg == 2) CALL_V(DD, 2, false);                  \
-    else if (use_seg && F.enabled) CALL_V(DD, 1, true);      \
+    else if (use_seg && F.enabled == 1) CALL_V(DD, 1, true);      \
     else if (use_seg) CALL_V(DD, 1, false);                  \
-    else if (F.enabled) CALL_V(DD, 0, true);                 \
+    else if (F.enabled == 1) CALL_V(DD, 0, true);                 \
     else CALL_V(DD, 0, false);                               \
   } while (0)
   ANN_DISPATCH_D(P.d, CALL);
@@ -799,14 +801,15 @@ static void launch_rows(const QParams &P, size_t Q, const FT *y, int alias, cons
   if (!nq) return;
   const int kq = (int)(qstride ? qstride : Q);  // stride of the code array (see launch_stage1)
   // long rows (exact path, a handful of rows) are split over up to 8 workgroups; short rows get one
-  const unsigned split = len >= 1024 ? 8 : 1;
+  // (device-driven launches expect a handful of rows, each on a step's critical path: 32 workgroups per row)
+  const unsigned split = len >= 1024 ? (live_rows ? 32 : 8) : 1;
   u32 chunk = len < ANN_RD_CHUNK ? ((len + 63u) & ~63u) : ANN_RD_CHUNK;  // LDS lists sized to the row
-  if (split > 1) chunk = std::max<u32>(256, (((len + split - 1) / split) + 63u) & ~63u);
+  if (split > 1) chunk = std::max<u32>(live_rows ? 128 : 256, (((len + split - 1) / split) + 63u) & ~63u);
   if (chunk > ANN_RD_CHUNK) chunk = ANN_RD_CHUNK;
   const size_t smem = rows_lds_bytes(P, chunk);
   // short rows (stage 2 at small k): fewer waves per row, more rows resident per CU
   const unsigned block = len <= 128 ? 128 : 256;
-  const unsigned grid = live_rows ? (unsigned)std::min<size_t>(nq, 512) : (unsigned)nq;
+  const unsigned grid = live_rows ? (unsigned)std::min<size_t>(nq, split > 8 ? 64 : 512) : (unsigned)nq;
 #define CALL(DD)                                                                                         \
   do {                                                                                                   \
     allow_lds(row_dists_kernel<DD, MODE>, smem);                                                         \
@@ -942,7 +945,9 @@ static long finalize_and_fallback(annhip_index *ix, const QParams &P, size_t Q, 
                                   const u32 *codes, int mode, const FT *cand_d, const u32 *cand_i,
                                   const u32 *nvt, u32 *top_i, FT *top_d, int ostride, int ooff, DevBuf &flist,
                                   DevBuf &xids, DevBuf &xd, u32 *d_fcount, unsigned long long *rows_done,
-                                  unsigned long long *exact_total, bool device_driven, hipStream_t s, size_t qstride = 0) {
+                                  unsigned long long *exact_total, bool device_driven, hipStream_t s, size_t qstride = 0,
+                                  bool prefinalized = false) {
+  // prefinalized: stage 1 applied finalize1's test itself (FusedTail.enabled == 2): flist / *d_fcount / top_* are set
   const int K1 = P.k + 1;
   u32 nflag = 0;
   u32 *fl = (u32 *)flist.need(sizeof(u32) * Q);
@@ -950,10 +955,12 @@ static long finalize_and_fallback(annhip_index *ix, const QParams &P, size_t Q, 
   size_t chunk = env().exact_bytes / (row_bytes ? row_bytes : 1);
   if (chunk < 1) chunk = 1;
   if (mode == 0) {
-    zero_u32_kernel<<<1, 1, 0, s>>>(d_fcount);
-    hipLaunchKernelGGL(finalize1_kernel, dim3(grid_for(Q, 256, 1u << 30)), dim3(256), 0, s, (int)Q, P.k, K1, P.L1,
-                       P.P1, cand_d, cand_i, nvt, top_i, top_d, ostride, ooff, fl, d_fcount, exact_total);
-    HIPCHECK(hipGetLastError());
+    if (!prefinalized) {
+      zero_u32_kernel<<<1, 1, 0, s>>>(d_fcount);
+      hipLaunchKernelGGL(finalize1_kernel, dim3(grid_for(Q, 256, 1u << 30)), dim3(256), 0, s, (int)Q, P.k, K1, P.L1,
+                         P.P1, cand_d, cand_i, nvt, top_i, top_d, ostride, ooff, fl, d_fcount, exact_total);
+      HIPCHECK(hipGetLastError());
+    }
     if (device_driven && Q <= 8 * chunk) {
       // The workspace holds R = min(Q, chunk) rows; the flagged list is walked in passes of R entries, each pass
       // device-driven (a pass beyond the device-side count exits at once: two empty launches).  One pass covers
@@ -1037,9 +1044,13 @@ static long query_impl(annhip_index *ix, annhip_workspace &ws, hipStream_t s, si
   std::vector<hipEvent_t> marks_store, *marks = ix->profile ? &marks_store : NULL;
   seg_mark(ix, marks, s);
   const u32 *codes = codes_ext;
+  bool fcount_zeroed = false;
   if (!codes_ext) {
     u32 *own = (u32 *)ws.codes.need(sizeof(u32) * Q * P.T);
-    if (!codes_ready) launch_codes(P, codes_needed(ix, Q), y, own, s);
+    if (!codes_ready) {
+      launch_codes(P, codes_needed(ix, Q), y, own, s, ws.d_fcount);  // also resets the batch's flagged-query counter
+      fcount_zeroed = codes_needed(ix, Q) > 0;
+    }
     codes = own;
   } else if (ix->fixed) {
     die("annhip_query_slice: not available in fixed mode");
@@ -1087,8 +1098,8 @@ static long query_impl(annhip_index *ix, annhip_workspace &ws, hipStream_t s, si
       FT *out_d = dists_dev ? reinterpret_cast<FT *>(dists_dev) : (FT *)ws.out_d.need(sizeof(FT) * Q * k);
       u32 *fl = (u32 *)ws.flist.need(sizeof(u32) * Q);
       u32 *nvo = (u32 *)ws.nvo.need(sizeof(u32) * Q);
-      zero_u32_kernel<<<1, 1, 0, s>>>(ws.d_fcount);
-      FusedTail F{1, P.Lc2, ids_dev, out_d, fl, ws.d_fcount, ix->d_rows + 2};
+      if (!fcount_zeroed) zero_u32_kernel<<<1, 1, 0, s>>>(ws.d_fcount);
+      FusedTail F{1, P.Lc2, ids_dev, out_d, fl, ws.d_fcount, ix->d_rows + 2, NULL, NULL};
       cand_d = (FT *)ws.cand_d.need(sizeof(FT) * Q * K1);  // written for rejected queries only
       cand_i = (u32 *)ws.cand_i.need(sizeof(u32) * Q * K1);
       launch_stage1(ix, P, Q, y, alias, codes, cand_d, cand_i, NULL, nvo, s, ix->h_tries, ix->use_seg, F);
@@ -1113,18 +1124,25 @@ static long query_impl(annhip_index *ix, annhip_workspace &ws, hipStream_t s, si
       return -1;
     }
   }
+  bool prefinalized = false;
   if (mode == 0) {
     cand_d = (FT *)ws.cand_d.need(sizeof(FT) * Q * K1);
     cand_i = (u32 *)ws.cand_i.need(sizeof(u32) * Q * K1);
     nvt = (u32 *)ws.nvt.need(sizeof(u32) * Q);
     u32 *nvo = (u32 *)ws.nvo.need(sizeof(u32) * Q);
+    // finalize1's test runs in the tail of the stage-1 workgroups (no finalize1 launch, no counter-reset launch)
+    u32 *fl = (u32 *)ws.flist.need(sizeof(u32) * Q);
+    prefinalized = env().fin_tail != 0;
+    if (prefinalized && !fcount_zeroed) zero_u32_kernel<<<1, 1, 0, s>>>(ws.d_fcount);
     launch_stage1(ix, P, Q, y, alias, codes, cand_d, cand_i, nvt, nvo, s, ix->h_tries, ix->use_seg,
-                  FusedTail{0, 0, NULL, NULL, NULL, NULL, NULL}, NULL, 1, env().s1_slots, qstride);
+                  FusedTail{prefinalized ? 2 : 0, 0, NULL, NULL, fl, ws.d_fcount, ix->d_rows + 2, top_i, top_d}, NULL, 1,
+                  env().s1_slots, qstride);
   }
   seg_mark(ix, marks, s);
   unsigned long long *rows_ctr = ix->profile ? ix->d_rows + 8 : NULL;
   long nflag = finalize_and_fallback(ix, P, Q, y, alias, codes, mode, cand_d, cand_i, nvt, top_i, top_d, k, 0,
-                                     ws.flist, ws.xids, ws.xd, ws.d_fcount, rows_ctr, ix->d_rows + 2, true, s, qstride);
+                                     ws.flist, ws.xids, ws.xd, ws.d_fcount, rows_ctr, ix->d_rows + 2, true, s, qstride,
+                                     prefinalized);
   seg_mark(ix, marks, s);
   // stage 2 (det_results second half, alg.c:314-327)
   FT *out_d = dists_dev ? reinterpret_cast<FT *>(dists_dev) : (FT *)ws.out_d.need(sizeof(FT) * Q * k);
@@ -1356,7 +1374,7 @@ extern "C" void annhip_sh_stage1(annhip_index *ix, void *hip_stream, size_t Q, c
   const QParams P = make_params(ix);
   if ((u32)P.k > P.P1) die("annhip_sh_stage1: k exceeds the sorted prefix; use the exact path (annhip_stage1_rows)");
   launch_stage1(ix, P, Q, reinterpret_cast<const FT *>(y_dev), alias, codes_dev, NULL, NULL, nvalid_dev, nown_dev,
-                (hipStream_t)hip_stream, ix->h_tries, ix->use_seg, FusedTail{0, 0, NULL, NULL, NULL, NULL, NULL},
+                (hipStream_t)hip_stream, ix->h_tries, ix->use_seg, FusedTail{0, 0, NULL, NULL, NULL, NULL, NULL, NULL, NULL},
                 reinterpret_cast<Key *>(keys_dev), ix->gather_pieces, ix->gather_slots);
   ix->queries += (double)Q;
 }

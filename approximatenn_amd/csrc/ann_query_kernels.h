@@ -101,8 +101,10 @@ __device__ __forceinline__ int oc_tree_len(int d) { return OcCode<D>::UA ? d : 0
 #define ANN_CODES_QPB 64
 template <int D>
 __global__ __launch_bounds__(256) void codes_kernel(QParams P, int Q, const FT *__restrict__ y,
-                                                    u32 *__restrict__ codes) {
+                                                    u32 *__restrict__ codes, u32 *__restrict__ zero_me) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // the batch's flagged-query counter is reset here: a launch of its own cost ~5 us of every step
+  if (zero_me && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *zero_me = 0;
   const int lane = lane_id(), w = threadIdx.x >> 6, wpb = blockDim.x >> 6;
   if constexpr (D > 0) {
     typedef RowLay<D> L;
@@ -796,12 +798,15 @@ __global__ __launch_bounds__(256) void stage2_select_kernel(QParams P, int Q, co
 // network on the L2-entry row in LDS and writes the final size_t ids and distances.  Rejected queries are appended to
 // `flist`; the host runs the separate exact path for them afterwards (device-driven, normally zero rows).
 struct FusedTail {
-  int enabled;          // 0: classic path (multi-GPU staged calls, precomp, long stage-2 rows)
+  int enabled;          // 0: classic path (multi-GPU staged calls, precomp); 1: stage 2 in the workgroup's tail;
+                        // 2: finalize1's test in the tail (accepted: top_id/top_dist, rejected: flist) -- no finalize1 launch
   u32 len2;             // Lc2 = ann_need_len(L2, k)
   size_t *out_ids;      // [Q][k]
   FT *out_dist;         // [Q][k]
   u32 *flist, *fcount;  // rejected queries
   unsigned long long *exact_total;
+  u32 *top_id;          // enabled == 2: [Q][k]
+  FT *top_dist;
 };
 
 template <int D, int SEG, bool FUSED>  // SEG: 0 = slot scan, 1 = segment words + table rows, 2 = inline 32-byte records
@@ -1036,6 +1041,25 @@ __global__ __launch_bounds__(256) void stage1_select_kernel(QParams P, int Q, co
       if (lane == 0) {
         nv_tot[x] = cnts[0];
         nv_own[x] = cnts[1];  // per-query count; never a same-address atomic from every workgroup (fan-in ~12 ns each)
+      }
+      if (F.enabled == 2) {  // finalize1's test here (see finalize1_kernel): one launch and its drain less per step
+        const int k = K1 - 1;
+        bool bad = m < k;
+        for (int t = lane; t + 1 < m; t += ANN_WAVE)
+          if (ft_bits(key_dist(S.kout[t])) == ft_bits(key_dist(S.kout[t + 1]))) bad = true;
+        if (m >= k && !(key_dist(S.kout[k - 1]) < ft_inf())) bad = true;
+        if (P.L1 > P.P1 && cnts[0] >= P.P1) bad = true;
+        if (__ballot(bad) != 0) {
+          if (lane == 0) {
+            F.flist[atomicAdd(F.fcount, 1u)] = x;
+            if (F.exact_total) atomicAdd(F.exact_total, 1ull);
+          }
+        } else {
+          for (int t = lane; t < k; t += ANN_WAVE) {
+            F.top_id[(size_t)x * k + t] = key_id(S.kout[t]);
+            F.top_dist[(size_t)x * k + t] = key_dist(S.kout[t]);
+          }
+        }
       }
     } else {
       // the finalize1 test (see finalize1_kernel): >= k finite distinct keys, no shared distance, an +inf in the prefix
@@ -1455,7 +1479,6 @@ __global__ __launch_bounds__(1024) void exact_select_kernel(u32 L, u32 len, u32 
                                                            int ooff, const u32 *__restrict__ live_rows,
                                                            u32 nrows, size_t *__restrict__ out64, u32 live_off, TieArgs T) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ int tie_ok;
   if (live_rows) nrows = min(nrows, max(*live_rows, live_off) - live_off);  // persistent grid over the device-side row count
   for (u32 row = blockIdx.x; row < nrows; row += gridDim.x) {
   const u32 x = qidx ? qidx[row] : xbase + row;
@@ -1463,19 +1486,13 @@ __global__ __launch_bounds__(1024) void exact_select_kernel(u32 L, u32 len, u32 
   FT *gd = dist_in + (size_t)row * in_stride;
   if constexpr (NW > 0) {
     if (T.cand_d) {  // workgroup-uniform
-      if (threadIdx.x < ANN_WAVE) {
-        const size_t o = (size_t)x * ostride + ooff;
-        const bool ok = tie_resolve<NW>(L, k, T.K1, gi, gd, T.cand_d + (size_t)x * T.K1, T.cand_i + (size_t)x * T.K1, smem,
-                                        out64 ? NULL : out_id + o, out64 ? out64 + o : NULL, out_dist + o);
-        if (threadIdx.x == 0) {
-          tie_ok = ok ? 1 : 0;
-          if (ok && T.resolved) atomicAdd(T.resolved, 1ull);
-        }
+      const size_t o = (size_t)x * ostride + ooff;
+      const bool done = tie_resolve<NW>(L, k, T.K1, gi, gd, T.cand_d + (size_t)x * T.K1, T.cand_i + (size_t)x * T.K1, smem,
+                                        out64 ? NULL : out_id + o, out64 ? out64 + o : NULL, out_dist + o, T.resolved);
+      if (done) {
+        if (threadIdx.x == 0 && T.resolved) atomicAdd(T.resolved, 1ull);
+        continue;
       }
-      __syncthreads();
-      const bool done = tie_ok != 0;
-      __syncthreads();  // tie_ok and the LDS are re-used
-      if (done) continue;
     }
   }
   if (USE_LDS) {

@@ -361,6 +361,7 @@ def main():
                        "L2": ix.L2, "P2": ix.P2, "sum_par_maxes": ix.sum_pm, "datagen_s": round(datagen_s, 2),
                        "precomp_s": round(precomp_s, 2),
                        "exact_path_queries_per_step": round(st["exact_queries"] / args.steps, 2),
+                       "tie_path_queries_per_step": round(st.get("tie_queries", 0) / args.steps, 2),
                        "host_submit_ms_per_step": round(submit_s / args.steps * 1e3, 4)},
             "roofline": roofline}
     if stage_ms:
