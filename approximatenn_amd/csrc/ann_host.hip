@@ -276,9 +276,12 @@ struct annhip_index {
   annhip_workspace ws;           // default workspace (annhip_query, staged calls)
   DevBuf io_y, io_ids, io_dist;  // query_gpu's staging of host inputs/outputs, reused between calls
   PinBuf io_y_pin, io_out_pin;   // ... and their pinned host-side bounce buffers
+  hipStream_t io_copy_stream = NULL;      // query_gpu: the batch's pieces cross PCIe on this stream while the main stream hashes
+  std::vector<hipEvent_t> io_ev;          // ... one event per piece
   unsigned long long *d_rows = NULL;  // [0] stage-1 gathered rows, [2] exact-path queries, [3] of those: answered by the tie path, [8..8+512) rows kernels (64 padded shards)
   // measurement
-  bool profile = false;
+  int profile = 0;  // 1: stage-1 event pair + stage marks + row statistics; 2: the stage-1 event pair only (two events per
+                    // step: what bench.py keeps inside its timed region; every event costs ~5 us of stream time)
   std::vector<EventPair> ev_used, ev_free;
   std::vector<hipEvent_t> seg_free;
   std::vector<std::vector<hipEvent_t>> seg_used;  // per call: events at the stage boundaries
@@ -467,6 +470,8 @@ extern "C" void annhip_index_destroy(annhip_index *ix) {
   ix->ws.release();
   ix->io_y.release(), ix->io_ids.release(), ix->io_dist.release();
   ix->io_y_pin.release(), ix->io_out_pin.release();
+  for (hipEvent_t e : ix->io_ev) (void)hipEventDestroy(e);
+  if (ix->io_copy_stream) (void)hipStreamDestroy(ix->io_copy_stream);
   for (auto &e : ix->ev_used) (void)hipEventDestroy(e.a), (void)hipEventDestroy(e.b);
   for (auto &e : ix->ev_free) (void)hipEventDestroy(e.a), (void)hipEventDestroy(e.b);
   for (hipEvent_t e : ix->seg_free) (void)hipEventDestroy(e);
@@ -740,7 +745,7 @@ static void launch_stage1(annhip_index *ix, const QParams &P, size_t Q, const FT
     HIPCHECK(hipEventRecord(ev.b, s));
     ix->ev_used.push_back(ev);
     // gathered-row statistics only while measuring: one small reduction kernel, outside the event bracket
-    sum_u32_kernel<<<grid_for(Q, 256, 64), 256, 0, s>>>(Q, nvo, ix->d_rows);
+    if (ix->profile == 1) sum_u32_kernel<<<grid_for(Q, 256, 64), 256, 0, s>>>(Q, nvo, ix->d_rows);
   }
   if (ix) ix->s1_launches += 1;
 }
@@ -1031,8 +1036,8 @@ static size_t codes_needed(const annhip_index *ix, size_t Q) {
 // codes_ext / qstride: the batch is a SLICE of a larger one whose codes (try-major reads, stride qstride) the caller holds:
 // codes_ext points at the slice's first query (annhip_query_slice).
 static long query_impl(annhip_index *ix, annhip_workspace &ws, hipStream_t s, size_t Q, const ftype *y_dev, int alias,
-                       int mode, size_t *ids_dev, ftype *dists_dev, bool codes_ready = false, const u32 *codes_ext = NULL,
-                       size_t qstride = 0) {
+                       int mode, size_t *ids_dev, ftype *dists_dev, int codes_ready = 0, const u32 *codes_ext = NULL,
+                       size_t qstride = 0) {  // codes_ready: 1 = ws.codes holds the batch's codes, 2 = and ws.d_fcount has been reset
   if (!Q) return 0;
   if (Q >= 0x7FFFFFFFull / (size_t)(ix->T > 0 ? ix->T : 1)) die("query batch too large");
   const QParams P = make_params(ix);
@@ -1041,10 +1046,10 @@ static long query_impl(annhip_index *ix, annhip_workspace &ws, hipStream_t s, si
   const int k = P.k, K1 = k + 1;
   if (env().exact) mode = 1;
   if ((u32)k > P.P1) mode = 1;
-  std::vector<hipEvent_t> marks_store, *marks = ix->profile ? &marks_store : NULL;
+  std::vector<hipEvent_t> marks_store, *marks = ix->profile == 1 ? &marks_store : NULL;
   seg_mark(ix, marks, s);
   const u32 *codes = codes_ext;
-  bool fcount_zeroed = false;
+  bool fcount_zeroed = codes_ready == 2;
   if (!codes_ext) {
     u32 *own = (u32 *)ws.codes.need(sizeof(u32) * Q * P.T);
     if (!codes_ready) {
@@ -1078,7 +1083,7 @@ static long query_impl(annhip_index *ix, annhip_workspace &ws, hipStream_t s, si
     seg_mark(ix, marks, s);
     FT *out_d = dists_dev ? reinterpret_cast<FT *>(dists_dev) : (FT *)ws.out_d.need(sizeof(FT) * Q * k);
     if (!stage2_select_with_fallback(P, Q, y, alias, 0, Q, top_i, top_d, NULL, ids_dev, out_d, ws.flist, ws.d_fcount, ws.r2i,
-                                     ws.r2d, NULL, ix->profile ? ix->d_rows + 8 : NULL, s))
+                                     ws.r2d, NULL, ix->profile == 1 ? ix->d_rows + 8 : NULL, s))
       die("fixed mode: stage-2 shape not supported");
     seg_mark(ix, marks, s);
     seg_mark(ix, marks, s);
@@ -1105,7 +1110,7 @@ static long query_impl(annhip_index *ix, annhip_workspace &ws, hipStream_t s, si
       launch_stage1(ix, P, Q, y, alias, codes, cand_d, cand_i, NULL, nvo, s, ix->h_tries, ix->use_seg, F);
       seg_mark(ix, marks, s);
       // rejected queries (device-side count, normally zero): exact stage 1, then the classic stage 2, for them only
-      unsigned long long *rows_ctr = ix->profile ? ix->d_rows + 8 : NULL;
+      unsigned long long *rows_ctr = ix->profile == 1 ? ix->d_rows + 8 : NULL;
       u32 *xi = (u32 *)ws.xids.need(sizeof(u32) * Q * P.Lc1);
       FT *xd = (FT *)ws.xd.need(sizeof(FT) * Q * P.Lc1);
       launch_rows<MODE_TABLE>(P, Q, y, alias, codes, fl, 0, Q, P.Lc1, NULL, NULL, xi, xd, rows_ctr, s, ws.d_fcount);
@@ -1139,7 +1144,7 @@ static long query_impl(annhip_index *ix, annhip_workspace &ws, hipStream_t s, si
                   env().s1_slots, qstride);
   }
   seg_mark(ix, marks, s);
-  unsigned long long *rows_ctr = ix->profile ? ix->d_rows + 8 : NULL;
+  unsigned long long *rows_ctr = ix->profile == 1 ? ix->d_rows + 8 : NULL;
   long nflag = finalize_and_fallback(ix, P, Q, y, alias, codes, mode, cand_d, cand_i, nvt, top_i, top_d, k, 0,
                                      ws.flist, ws.xids, ws.xd, ws.d_fcount, rows_ctr, ix->d_rows + 2, true, s, qstride,
                                      prefinalized);
@@ -1310,7 +1315,7 @@ extern "C" void annhip_stage1_rows(annhip_index *ix, size_t Q, const ftype *y_de
                                    uint32_t *ids_dev, ftype *dist_dev) {
   const QParams P = make_params(ix);
   launch_rows<MODE_TABLE>(P, Q, reinterpret_cast<const FT *>(y_dev), alias, codes_dev, qidx_dev, 0, nq, P.Lc1, NULL,
-                          NULL, ids_dev, reinterpret_cast<FT *>(dist_dev), ix->profile ? ix->d_rows + 8 : NULL, ix->stream);
+                          NULL, ids_dev, reinterpret_cast<FT *>(dist_dev), ix->profile == 1 ? ix->d_rows + 8 : NULL, ix->stream);
 }
 
 extern "C" void annhip_exact_select(annhip_index *ix, int stage, size_t nq, uint32_t *ids_dev, ftype *dist_dev,
@@ -1414,7 +1419,7 @@ extern "C" void annhip_sh_exact1_begin(annhip_index *ix, void *hip_stream, size_
                      (u32)fcap, flist_dev);
   HIPCHECK(hipGetLastError());
   launch_rows<MODE_TABLE>(P, Q, reinterpret_cast<const FT *>(y_dev), alias, codes_dev, flist_dev + 2, 0, fcap, P.Lc1, NULL,
-                          NULL, rows_id_dev, reinterpret_cast<FT *>(rows_dist_dev), ix->profile ? ix->d_rows + 8 : NULL, s,
+                          NULL, rows_id_dev, reinterpret_cast<FT *>(rows_dist_dev), ix->profile == 1 ? ix->d_rows + 8 : NULL, s,
                           flist_dev);
 }
 
@@ -1438,7 +1443,7 @@ extern "C" void annhip_sh_stage2(annhip_index *ix, void *hip_stream, size_t Q, c
   hipStream_t s = (hipStream_t)hip_stream;
   zero_u32_kernel<<<1, 1, 0, s>>>(flagged_dev);  // flagged_dev = {count, query indices...}, Q + 1 entries
   launch_rows<MODE_GRAPH_DIST>(P, Q, reinterpret_cast<const FT *>(y_dev), alias, NULL, NULL, 0, Q, P.Lc2, top_id_all_dev,
-                               NULL, flagged_dev, reinterpret_cast<FT *>(dist_out_dev), ix->profile ? ix->d_rows + 8 : NULL, s);
+                               NULL, flagged_dev, reinterpret_cast<FT *>(dist_out_dev), ix->profile == 1 ? ix->d_rows + 8 : NULL, s);
 }
 
 extern "C" void annhip_sh_final(annhip_index *ix, void *hip_stream, int ndev, size_t Q, size_t q_lo, size_t qs,
@@ -1467,7 +1472,7 @@ extern "C" void annhip_stage2_rows_list(annhip_index *ix, size_t Q, const ftype 
   const QParams P = make_params(ix);
   launch_rows<MODE_GRAPH>(P, Q, reinterpret_cast<const FT *>(y_dev), alias, NULL, qidx_dev, 0, nq, P.Lc2, top_id_dev,
                           reinterpret_cast<const FT *>(top_dist_dev), ids_dev, reinterpret_cast<FT *>(dist_dev),
-                          ix->profile ? ix->d_rows + 8 : NULL, ix->stream);
+                          ix->profile == 1 ? ix->d_rows + 8 : NULL, ix->stream);
 }
 
 // ---- content checksums (multi-GPU hosts prove with them that every rank holds the same index and the same batch;
@@ -1533,7 +1538,7 @@ extern "C" unsigned long long annhip_index_checksum(annhip_index *ix) {
   return h;
 }
 
-extern "C" void annhip_profile(annhip_index *ix, int profile) { ix->profile = profile != 0; }
+extern "C" void annhip_profile(annhip_index *ix, int profile) { ix->profile = profile == 2 ? 2 : profile != 0; }
 
 extern "C" void annhip_stats(annhip_index *ix, double out[8], int reset) {
   HIPCHECK(hipStreamSynchronize(ix->stream));
@@ -2224,9 +2229,9 @@ extern "C" size_t annhip_cache_size(void) { return g_cache.size(); }
 extern "C" void annhip_host_profile(int on) {
   g_host_profile = on != 0;
   for (auto &e : g_cache) {
-    if (e.ix) e.ix->profile = g_host_profile;
+    if (e.ix) e.ix->profile = g_host_profile ? 1 : 0;
     if (e.multi)
-      for (auto &S : e.multi->sh) S.ix->profile = g_host_profile;
+      for (auto &S : e.multi->sh) S.ix->profile = g_host_profile ? 1 : 0;
   }
 }
 // shard < 0: the whole resident index (a sharded one: launches and milliseconds of the slowest shard, rows summed)
@@ -2288,7 +2293,7 @@ static void cache_put(const save_t *sv, const ftype *points, u64 fp, annhip_inde
     entry_destroy(g_cache.front());
     g_cache.erase(g_cache.begin());
   }
-  if (ix) ix->profile = g_host_profile;
+  if (ix) ix->profile = g_host_profile ? 1 : 0;
   g_cache.push_back(CacheEntry{sv, points, sv->graph, sv->n, sv->k, sv->d_long, sv->tries, fp, ix, multi});
 }
 
@@ -2386,10 +2391,20 @@ static void query_single_begin(annhip_index *ix, size_t ycnt, const ftype *y, in
   hipStream_t s = ix->stream;
   const QParams P = make_params(ix);
   const size_t row = sizeof(FT) * d, hashed = codes_needed(ix, ycnt);
-  static const int io_pieces = env_int("ANN_HIP_IO_PIECES", 2);
-  const size_t pieces = std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, io_pieces), ycnt * row >> 20));
+  static const int io_pieces = env_int("ANN_HIP_IO_PIECES", 4);
+  const size_t pieces = std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, std::min(io_pieces, 16)), ycnt * row >> 20));
   const size_t per = (ycnt + pieces - 1) / pieces;
   u32 *codes = (u32 *)ix->ws.codes.need(sizeof(u32) * ycnt * P.T);
+  if (!ix->ws.d_fcount) ix->ws.d_fcount = dev_alloc<u32>(4);
+  // The pieces cross PCIe back to back on a stream of their own; the main stream hashes piece i (an event away) while
+  // piece i+1 is on the wire -- only the last piece's hash is left in front of stage 1 (which needs every code, Q2).
+  if (!ix->io_copy_stream) HIPCHECK(hipStreamCreateWithFlags(&ix->io_copy_stream, hipStreamNonBlocking));
+  while (ix->io_ev.size() < pieces) {
+    hipEvent_t e;
+    HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ix->io_ev.push_back(e);
+  }
+  hipStream_t cs = pieces > 1 ? ix->io_copy_stream : s;
   std::vector<std::atomic<int>> copied(pieces);
   for (auto &c : copied) c.store(0, std::memory_order_relaxed);
   // every piece is itself copied by several pool threads: items = pieces x lanes, taken in order
@@ -2402,16 +2417,24 @@ static void query_single_begin(annhip_index *ix, size_t ycnt, const ftype *y, in
     copied[i].fetch_add(1, std::memory_order_release);
   };
   HostPool::get().begin(pieces * lanes, copy_part);
+  bool zeroed = false;
   for (size_t i = 0; i < pieces; i++) {
     const size_t q0 = i * per, nq = q0 < ycnt ? std::min(per, ycnt - q0) : 0;
     while ((size_t)copied[i].load(std::memory_order_acquire) < lanes) {
     }
     if (!nq) continue;
     const size_t bytes = nq * row;  // rows are multiples of 4 bytes at least; the tail handles what is not 16
-    copy_in_kernel<<<grid_for(bytes / 16 ? bytes / 16 : 1, 256, 512), 256, 0, s>>>(
+    copy_in_kernel<<<grid_for(bytes / 16 ? bytes / 16 : 1, 256, 512), 256, 0, cs>>>(
         bytes / 16, reinterpret_cast<const copy_vec4 *>(y_pin_dev + q0 * row), reinterpret_cast<copy_vec4 *>((char *)y_dev + q0 * row),
         bytes % 16, bytes);
-    if (q0 < hashed) launch_codes(P, std::min(nq, hashed - q0), y_dev + q0 * d, codes + q0 * P.T, s);
+    if (cs != s) {
+      HIPCHECK(hipEventRecord(ix->io_ev[i], cs));
+      HIPCHECK(hipStreamWaitEvent(s, ix->io_ev[i], 0));
+    }
+    if (q0 < hashed) {
+      launch_codes(P, std::min(nq, hashed - q0), y_dev + q0 * d, codes + q0 * P.T, s, zeroed ? NULL : ix->ws.d_fcount);
+      zeroed = true;
+    }
   }
   HIPCHECK(hipGetLastError());
   HostPool::get().end();
@@ -2421,7 +2444,7 @@ static void query_single_begin(annhip_index *ix, size_t ycnt, const ftype *y, in
   char *out_pin = (char *)ix->io_out_pin.need(ib + db);
   char *out_dev = (char *)pinned_dev_ptr(out_pin);
   query_impl(ix, ix->ws, s, ycnt, reinterpret_cast<const ftype *>(y_dev), alias, 0, reinterpret_cast<size_t *>(out_dev),
-             reinterpret_cast<ftype *>(out_dev + ib), true);
+             reinterpret_cast<ftype *>(out_dev + ib), zeroed ? 2 : 1);
   (void)want_d;
   tmark(2);
 }
@@ -2429,6 +2452,10 @@ static void query_single_begin(annhip_index *ix, size_t ycnt, const ftype *y, in
 static void query_single_end(annhip_index *ix, size_t ycnt, size_t *result, ftype *dists) {
   const size_t ib = sizeof(size_t) * ycnt * ix->k, db = dists ? sizeof(FT) * ycnt * ix->k : 0;
   tmark(3);
+  // the caller's result arrays are fresh mmap'd memory: their first touch (a page fault per 4 KB, ~50 us for a cfg3
+  // batch) happens here, while the GPU works, instead of inside the copy below
+  for (size_t o = 0; o < ib; o += 4096) reinterpret_cast<volatile char *>(result)[o] = 0;
+  for (size_t o = 0; o < db; o += 4096) reinterpret_cast<volatile char *>(dists)[o] = 0;
   HIPCHECK(hipStreamSynchronize(ix->stream));
   tmark(4);
   const char *out_pin = (const char *)ix->io_out_pin.p;

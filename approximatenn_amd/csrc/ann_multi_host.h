@@ -279,7 +279,7 @@ static annhip_multi *multi_create(const MultiCfg &cfg, const save_t *save, const
     MultiShard &S = M->sh[g];
     S.ix = annhip_index_create(save, points + S.lo * save->d_long, 0, S.lo, S.hi);
     S.ix->stream = S.s;
-    S.ix->profile = g_host_profile;
+    S.ix->profile = g_host_profile ? 1 : 0;
   }, true);
   return M;
 }
@@ -552,7 +552,7 @@ static annhip_multi *multi_precomp(const MultiCfg &cfg, size_t n, size_t k, size
     HIPCHECK(hipFree(ga[g]));
     HIPCHECK(hipFree(gda[g]));
     S.ix->stream = S.s;
-    S.ix->profile = g_host_profile;
+    S.ix->profile = g_host_profile ? 1 : 0;
   }, true);
   if (M->virt) {  // all shards borrow shard 0's full copy, which this host takes over
     annhip_index *i0 = M->sh[0].ix;

@@ -315,11 +315,24 @@ def main():
     run_steps(batches[:args.warmup])
     torch.cuda.synchronize()
     ix.stats(reset=True)
-    ix.profile(os.environ.get("ANN_BENCH_NO_EVENTS") != "1")
+    # Inside the timed region: ONLY the HIP-event pair around each stage-1 launch (the roofline's kernel time, measured on
+    # the steps that count).  Every event record costs ~5 us of stream time, so the per-stage marks (8 more events per
+    # step) and the gathered-row statistics (one more small kernel per step) come from a SEPARATE, untimed pass over the
+    # same K batches right afterwards -- same batches, same rows, same flagged queries.
+    ix.profile(2 if os.environ.get("ANN_BENCH_NO_EVENTS") != "1" else 0)
     elapsed, submit_s = timed(batches[args.warmup:])
     st = ix.stats()
+    ix.profile(True)
+    ix.stats(reset=True)
+    run_steps(batches[args.warmup:])
+    torch.cuda.synchronize()
+    st_full = ix.stats()
     stage_ms = ix.stage_ms() if not sharded else None
     ix.profile(False)
+    if not st["s1_launches"]:  # ANN_BENCH_NO_EVENTS=1: no kernel time from the timed region; report the separate pass's
+        st["s1_launches"], st["s1_ms"] = st_full["s1_launches"], st_full["s1_ms"]
+    for key in ("s1_rows", "other_rows", "queries", "exact_queries", "tie_queries"):
+        st[key] = st_full[key]
 
     # ---- roofline of the dominant kernel (stage1_select): algorithmic bytes / HIP-event time
     launches = max(st["s1_launches"], 1.0)
@@ -366,6 +379,8 @@ def main():
             "roofline": roofline}
     if stage_ms:
         line["config"]["stage_ms_per_step"] = {k_: round(v / args.steps, 4) for k_, v in stage_ms.items()}
+        line["config"]["stage_ms_source"] = ("a separate untimed pass over the same batches with 8 more HIP events per step (~5 us "
+                                             "each); the timed region carries only the event pair around stage 1")
     if runner is not None:
         line["config"]["exchange"] = runner.exchange
         line["config"]["rccl"] = rccl
