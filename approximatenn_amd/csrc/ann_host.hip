@@ -77,6 +77,7 @@ struct EnvCfg {
   int cache_mode = 0;  // ANN_HIP_CACHE: 0 sampled fingerprint (default), 1 strict (full content hash), 2 off
   size_t bk_group = 0;  // ANN_HIP_BK_GROUP: cap on the members per pass of precomp's bucket kernel (0 = what fits the LDS)
   int fin_tail = 1;     // ANN_HIP_FIN_TAIL: 0 = finalize1 as its own launch after stage 1 (A/B; default: in the stage-1 workgroups' tail)
+  int codes_lpq = 1;    // ANN_HIP_CODES_LPQ: 0 = the lanes-per-row hash kernel for every row length (A/B)
   int tie = 1;          // ANN_HIP_TIE: 0 = flagged rows always take the literal network (no tie path, ann_tie.h)
 };
 static EnvCfg g_env;
@@ -107,6 +108,7 @@ static void load_env() {
   c.exact_rows = env_size("ANN_HIP_EXACT_ROWS", 0);
   c.bk_group = env_size("ANN_HIP_BK_GROUP", 0);
   c.tie = env_int("ANN_HIP_TIE", 1);
+  c.codes_lpq = env_int("ANN_HIP_CODES_LPQ", 1);
   c.fin_tail = env_int("ANN_HIP_FIN_TAIL", 1);
   const char *cm = getenv("ANN_HIP_CACHE");
   c.cache_mode = !cm ? 0 : !strcmp(cm, "strict") ? 1 : !strcmp(cm, "off") ? 2 : 0;
@@ -607,6 +609,15 @@ static void allow_lds(K kernel, size_t bytes) {
     HIPCHECK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
 }
 
+template <int DD>
+static void launch_codes_lpq_d(const QParams &P, size_t Q, const FT *y, u32 *codes, hipStream_t s, u32 *zero_me, dim3 grid,
+                               size_t smem) {
+  if constexpr (DD > 0 && DD * sizeof(FT) <= 512) {
+    allow_lds(codes_lpq_kernel<DD>, smem);
+    hipLaunchKernelGGL(codes_lpq_kernel<DD>, grid, dim3(64), smem, s, P, (int)Q, y, codes, zero_me);
+  }
+}
+
 // Qhash <= Q: only the first Qhash queries are hashed.  Stage 1 reads code[i*Q + x] for the tries i that own a
 // slot below Lc1, i.e. flat indices below tries_used*Q, i.e. queries below ceil(tries_used*Q/T).
 static void launch_codes(const QParams &P, size_t Qhash, const FT *y, u32 *codes, hipStream_t s, u32 *zero_me = NULL) {
@@ -614,7 +625,13 @@ static void launch_codes(const QParams &P, size_t Qhash, const FT *y, u32 *codes
   const size_t Q = Qhash;
   const size_t items = Q * (size_t)P.T;
   if (!items) return;
-  if (d_is_fast(P.d)) {  // workgroup = (try, run of queries); the try's projection rows live in LDS
+  if (d_is_fast(P.d) && (size_t)P.d * sizeof(FT) <= 512 && env().codes_lpq) {  // a lane per query (codes_lpq_kernel)
+    const size_t smem = sizeof(FT) * ((size_t)P.ds + 1) * P.d;
+    const dim3 grid((unsigned)((Q + ANN_WAVE - 1) / ANN_WAVE), (unsigned)P.T);
+#define CALL(DD) launch_codes_lpq_d<DD>(P, Q, y, codes, s, zero_me, grid, smem)
+    ANN_DISPATCH_D(P.d, CALL);
+#undef CALL
+  } else if (d_is_fast(P.d)) {  // workgroup = (try, run of queries); the try's projection rows live in LDS
     const size_t smem = sizeof(FT) * (size_t)P.ds * P.d;
     const dim3 grid((unsigned)((Q + ANN_CODES_QPB - 1) / ANN_CODES_QPB), (unsigned)P.T);
 #define CALL(DD)                                                                                      \

@@ -194,6 +194,65 @@ __global__ __launch_bounds__(256) void codes_kernel(QParams P, int Q, const FT *
   }
 }
 
+// Lane-per-query form of the hash for short power-of-two rows (d * s <= 512 bytes: d <= 128 float, 64 double).
+// codes_kernel spreads ONE row over 32 lanes and pays five cross-lane tree levels (a DPP move and two adds each) per
+// dot product: ~12 wave instructions per dot, 39 us per cfg3 batch.  Here a lane owns a whole query: its centred
+// row sits in registers (d of them), a projection row comes out of LDS as broadcast reads, and the pairwise tree of
+// compute.cl:160-167 runs literally, in the lane, on d/2 partial sums (level 1 fused with the products; the
+// reference's "+ 0" in every node kept, see row_reduce) -- ~3 d lane instructions per dot and no cross-lane traffic.
+// One 64-lane workgroup = (try, 64 queries).
+template <int D>
+__global__ __launch_bounds__(64) void codes_lpq_kernel(QParams P, int Q, const FT *__restrict__ y,
+                                                       u32 *__restrict__ codes, u32 *__restrict__ zero_me) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (zero_me && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *zero_me = 0;
+  constexpr int NC = D / ANN_VEC;  // 16-byte chunks per row
+  const int lane = lane_id(), t = blockIdx.y;
+  VT *rows = reinterpret_cast<VT *>(smem);  // [ds][NC], then the means [NC]
+  VT *mean = rows + (size_t)P.ds * NC;
+  const VT *src = reinterpret_cast<const VT *>(P.bases + (size_t)t * P.ds * D);
+  for (int i = lane; i < P.ds * NC; i += ANN_WAVE) rows[i] = src[i];
+  for (int i = lane; i < NC; i += ANN_WAVE) mean[i] = reinterpret_cast<const VT *>(P.means)[i];
+  wave_lds_sync();
+  const int q = blockIdx.x * ANN_WAVE + lane;
+  const bool live = q < Q;
+  const VT *yp = reinterpret_cast<const VT *>(y + (size_t)(live ? q : Q - 1) * D);
+  FT a[D];
+#pragma unroll
+  for (int c = 0; c < NC; c++) {
+    const VT yv = yp[c], mv = mean[c];
+    const FT *py = reinterpret_cast<const FT *>(&yv), *pm = reinterpret_cast<const FT *>(&mv);
+#pragma unroll
+    for (int j = 0; j < ANN_VEC; j++) a[c * ANN_VEC + j] = py[j] - pm[j];  // subtract_off, compute.cl:44-49
+  }
+  const FT zero = 0;
+  u32 code = 0;
+#pragma unroll 1
+  for (int s = 0; s < P.ds; s++) {
+    const VT *b = rows + (size_t)s * NC;
+    FT m[D / 2];
+#pragma unroll
+    for (int c = 0; c < NC / 2; c++) {  // products + the tree's first level: z with z + D/2
+      // (the scheduler would otherwise hoist all d/4 LDS reads of the row to the top: d more live registers)
+      if (c % 4 == 0 && c) __builtin_amdgcn_sched_barrier(0);
+      const VT b0 = b[c], b1 = b[c + NC / 2];
+      const FT *p0 = reinterpret_cast<const FT *>(&b0), *p1 = reinterpret_cast<const FT *>(&b1);
+#pragma unroll
+      for (int j = 0; j < ANN_VEC; j++) {
+        const int z = c * ANN_VEC + j;
+        m[z] = a[z] * p0[j] + (a[z + D / 2] * p1[j] + zero);
+      }
+    }
+#pragma unroll
+    for (int h = D / 4; h >= 1; h >>= 1)
+#pragma unroll
+      for (int z = 0; z < h; z++) m[z] = m[z] + (m[z + h] + zero);
+    const u32 sign = (u32)(ft_bits(m[0]) >> (sizeof(FT) * 8 - 1));
+    code |= sign << (P.ds - 1 - s);  // coord 0 = MSB, compute.cl:223-231
+  }
+  if (live) codes[(size_t)q * P.T + t] = code;
+}
+
 // id stored in slot j of query x's candidate row (compute_which, compute.cl:238-246; layout SURVEY Q9).
 // `tries`/`qcode` live in LDS.  ti is a cursor the caller may keep between increasing j.
 __device__ __forceinline__ u32 slot_id(const TryInfo *tries, const u32 *qcode, u32 j, int &ti) {
@@ -555,34 +614,51 @@ __device__ __forceinline__ u32 stage2_in_workgroup(const QParams &P, u32 x, int 
   }
   __syncthreads();
   const int cnt2 = (int)*cnt2p;
+  // U row passes are fetched before the first is reduced: written as load / reduce / store per pass the loop pays one
+  // memory round trip per pass (the LDS store of a distance orders it before the next pass's LDS read of an id) --
+  // 28 dependent round trips for the 55 rows of a cfg3 query on its one wave.
   if constexpr (D > 0) {
     typedef RowLay<D> L;
+    constexpr int U = 8 / L::C;
     const int p = lane % L::LPR, g = lane / L::LPR;
-    for (int base = w * L::RPW; base < cnt2; base += W * L::RPW) {
-      const int r = base + g;
-      const bool act = r < cnt2;
-      const u32 id = t_gid[act ? r : base];
-      const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(id - P.lo) * D) + p;
-      VT b[L::C];
+    for (int base0 = w * L::RPW; base0 < cnt2; base0 += W * L::RPW * U) {
+      VT b[U][L::C];
 #pragma unroll
-      for (int c = 0; c < L::C; c++) b[c] = load_row_chunk<true>(rp + c * L::LPR);
-      const FT dist = row_reduce<D, ROW_SQDIFF>(a, b);
-      if (act && p == 0) t_dist[t_slot[r]] = dist;
+      for (int u = 0; u < U; u++) {
+        const int r = base0 + u * W * L::RPW + g;
+        const u32 id = t_gid[r < cnt2 ? r : base0];
+        const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(id - P.lo) * D) + p;
+#pragma unroll
+        for (int c = 0; c < L::C; c++) b[u][c] = load_row_chunk<true>(rp + c * L::LPR);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int r = base0 + u * W * L::RPW + g;
+        const FT dist = row_reduce<D, ROW_SQDIFF>(a, b[u]);
+        if (r < cnt2 && p == 0) t_dist[t_slot[r]] = dist;
+      }
     }
   } else if constexpr (D < 0 && !OcCode<D>::GEN) {
     constexpr int C = OcCode<D>::C, OC = OcCode<D>::OC;
+    constexpr int U = C <= 2 ? 4 : 2;
     const OcLanes<D> ol(P.d, lane);
     const int oc = ol.oc, rpw = ol.rpw, g = ol.g, p = ol.p;
-    for (int base = w * rpw; base < cnt2; base += W * rpw) {
-      const int r = base + g;
-      const bool act = ol.valid && r < cnt2;
-      const u32 id = t_gid[act ? r : base];
-      const FT *rp = P.points + (size_t)(id - P.lo) * P.d;
-      VT b[C];
+    for (int base0 = w * rpw; base0 < cnt2; base0 += W * rpw * U) {
+      VT b[U][C];
 #pragma unroll
-      for (int c = 0; c < C; c++) b[c] = oc_load_chunk<D, OcCode<D>::NT_ROWS>(rp, p + c * oc, P.d);
-      const FT dist = row_reduce_oc<C, ROW_SQDIFF, OC>(a, b, oc, p, oc_tree_len<D>(P.d));
-      if (act && p == 0) t_dist[t_slot[r]] = dist;
+      for (int u = 0; u < U; u++) {
+        const int r = base0 + u * W * rpw + g;
+        const u32 id = t_gid[(ol.valid && r < cnt2) ? r : base0];
+        const FT *rp = P.points + (size_t)(id - P.lo) * P.d;
+#pragma unroll
+        for (int c = 0; c < C; c++) b[u][c] = oc_load_chunk<D, OcCode<D>::NT_ROWS>(rp, p + c * oc, P.d);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int r = base0 + u * W * rpw + g;
+        const FT dist = row_reduce_oc<C, ROW_SQDIFF, OC>(a, b[u], oc, p, oc_tree_len<D>(P.d));
+        if (ol.valid && r < cnt2 && p == 0) t_dist[t_slot[r]] = dist;
+      }
     }
   } else {
     for (int r = w; r < cnt2; r += W) {
@@ -1412,17 +1488,24 @@ __global__ __launch_bounds__(256) void row_dists_kernel(QParams P, int Q, const 
     gathered += cnt;
     if constexpr (D > 0) {
       typedef RowLay<D> L;
+      constexpr int U = 8 / L::C;  // row passes in flight (see stage2_in_workgroup)
       const int p = lane % L::LPR, g = lane / L::LPR;
-      for (int base = w * L::RPW; base < cnt; base += W * L::RPW) {
-        const int r = base + g;
-        const bool act = r < cnt;
-        const u32 id = lid[act ? r : base];
-        const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(id - P.lo) * D) + p;
-        VT b[L::C];
+      for (int base0 = w * L::RPW; base0 < cnt; base0 += W * L::RPW * U) {
+        VT b[U][L::C];
 #pragma unroll
-        for (int c = 0; c < L::C; c++) b[c] = load_row_chunk<true>(rp + c * L::LPR);
-        const FT dist = row_reduce<D, ROW_SQDIFF>(a, b);
-        if (act && p == 0) dist_row[lslot[r]] = dist;
+        for (int u = 0; u < U; u++) {
+          const int r = base0 + u * W * L::RPW + g;
+          const u32 id = lid[r < cnt ? r : base0];
+          const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(id - P.lo) * D) + p;
+#pragma unroll
+          for (int c = 0; c < L::C; c++) b[u][c] = load_row_chunk<true>(rp + c * L::LPR);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int r = base0 + u * W * L::RPW + g;
+          const FT dist = row_reduce<D, ROW_SQDIFF>(a, b[u]);
+          if (r < cnt && p == 0) dist_row[lslot[r]] = dist;
+        }
       }
     } else if constexpr (D < 0 && !OcCode<D>::GEN) {
       constexpr int C = OcCode<D>::C, OC = OcCode<D>::OC;
