@@ -831,13 +831,15 @@ static void launch_rows(const QParams &P, size_t Q, const FT *y, int alias, cons
   const size_t smem = rows_lds_bytes(P, chunk);
   // short rows (stage 2 at small k): fewer waves per row, more rows resident per CU
   const unsigned block = len <= 128 ? 128 : 256;
-  const unsigned grid = live_rows ? (unsigned)std::min<size_t>(nq, split > 8 ? 64 : 512) : (unsigned)nq;
+  // device-driven: a flat persistent grid over (row, part) items (see the kernel); otherwise one workgroup per (row, part)
+  const unsigned flat = live_rows ? split : 0;
+  const dim3 grid = live_rows ? dim3((unsigned)std::min<size_t>(nq * split, 512)) : dim3((unsigned)nq, split);
 #define CALL(DD)                                                                                         \
   do {                                                                                                   \
     allow_lds(row_dists_kernel<DD, MODE>, smem);                                                         \
-    hipLaunchKernelGGL((row_dists_kernel<DD, MODE>), dim3(grid, split), dim3(block), smem, s, P, kq, y, \
+    hipLaunchKernelGGL((row_dists_kernel<DD, MODE>), grid, dim3(block), smem, s, P, kq, y,               \
                        alias, codes, qidx, xbase, len, top_i, top_d, ids, dist, rows_done, live_rows,        \
-                       (u32)nq, chunk, live_off);                                                            \
+                       (u32)nq, chunk, live_off, flat);                                                      \
   } while (0)
   ANN_DISPATCH_D(P.d, CALL);
 #undef CALL
@@ -857,10 +859,16 @@ static void launch_exact_select(u32 L, u32 len, u32 in_stride, int k, size_t nq,
   // one pair per thread up to max_block.  1024 threads is the fastest shape on an idle GPU, but a 16-wave workgroup
   // cannot be placed while a saturating kernel of 1-wave workgroups keeps taking every freed slot (measured: 0.1 ms
   // alone, 1.1 ms = until the gather drained, next to the sharded stage 1): launches that run beside gathers use 256.
+  // Device-driven launches (normally nothing or a row or two to do, often beside other batches' kernels) use 256 too:
+  // with the tie path's registers a 16-wave workgroup needs a nearly empty CU, and even the launch that finds nothing to
+  // do has to be PLACED -- behind the stage-1 kernels of the other in-flight batches it serialised a three-lane
+  // pipeline of 1k-query batches (51 -> 86 us per batch).  The tie path scans a row with four waves just as well.
+  if (live_rows) max_block = std::min(max_block, 256u);
   unsigned block = npairs >= max_block ? max_block : ((npairs + 63) / 64) * 64;
   if (block < 64) block = 64;
   const size_t row_smem = (size_t)len * (sizeof(FT) + sizeof(u32));
-  const unsigned grid = live_rows ? (unsigned)std::min<size_t>(nq, 512) : (unsigned)nq;
+  // device-driven: a persistent grid of 128 workgroups (a launch of 512 x 16 waves that finds nothing to do cost ~10 us)
+  const unsigned grid = live_rows ? (unsigned)std::min<size_t>(nq, 128) : (unsigned)nq;
   const bool in_lds = row_smem <= env().lds_row_max;  // the whole row in LDS (a CU has 160 KB); longer rows sort in place in HBM
   const u32 Pn = (u32)1 << lk;
   int nw = 0;
@@ -2415,8 +2423,11 @@ static void query_single_begin(annhip_index *ix, size_t ycnt, const ftype *y, in
   if (!ix->ws.d_fcount) ix->ws.d_fcount = dev_alloc<u32>(4);
   // The pieces cross PCIe back to back on a stream of their own; the main stream hashes piece i (an event away) while
   // piece i+1 is on the wire -- only the last piece's hash is left in front of stage 1 (which needs every code, Q2).
-  if (!ix->io_copy_stream) HIPCHECK(hipStreamCreateWithFlags(&ix->io_copy_stream, hipStreamNonBlocking));
-  while (ix->io_ev.size() < pieces) {
+  // (created only when a batch is large enough to be sent in pieces: a process has four hardware queues by default, and a
+  // fifth stream shares one with somebody -- the mere existence of this stream took a three-lane annhip_stream pipeline
+  // of 1k-query batches from 51 to 72 us per batch)
+  if (pieces > 1 && !ix->io_copy_stream) HIPCHECK(hipStreamCreateWithFlags(&ix->io_copy_stream, hipStreamNonBlocking));
+  while (pieces > 1 && ix->io_ev.size() < pieces) {
     hipEvent_t e;
     HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     ix->io_ev.push_back(e);

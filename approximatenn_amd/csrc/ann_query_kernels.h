@@ -23,6 +23,13 @@
 #include "ann_device.h"
 #include "ann_tie.h"
 
+// Row passes fetched before the first is reduced in stage 2 / row_dists, in 16-byte chunks per lane.  1 = one pass at a
+// time.  Measured with 8: nothing at cfg3 (stage 2 is one 282-MB burst on HBM, not per-pass latency) and -19 % on the
+// fused small-batch kernel (registers); kept as an A/B knob.
+#ifndef ANN_ROWS_INFLIGHT
+#define ANN_ROWS_INFLIGHT 1
+#endif
+
 struct TryInfo {   // one try (= one random projection) of the index
   const u32 *tab;  // [2^ds][pm] bucket table, ids descending then padding n  (alg.c:261-266)
   const uint2 *seg;  // [2^ds] per bucket: x = first owned position | owned count << 16, y = valid count (see build_seg_kernel)
@@ -619,23 +626,27 @@ __device__ __forceinline__ u32 stage2_in_workgroup(const QParams &P, u32 x, int 
   // 28 dependent round trips for the 55 rows of a cfg3 query on its one wave.
   if constexpr (D > 0) {
     typedef RowLay<D> L;
-    constexpr int U = 8 / L::C;
+    constexpr int U = (ANN_ROWS_INFLIGHT / L::C) > 0 ? (ANN_ROWS_INFLIGHT / L::C) : 1;
     const int p = lane % L::LPR, g = lane / L::LPR;
     for (int base0 = w * L::RPW; base0 < cnt2; base0 += W * L::RPW * U) {
       VT b[U][L::C];
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const int r = base0 + u * W * L::RPW + g;
-        const u32 id = t_gid[r < cnt2 ? r : base0];
-        const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(id - P.lo) * D) + p;
+        if (base0 + u * W * L::RPW < cnt2) {  // wave-uniform: passes beyond the list are neither loaded nor reduced
+          const u32 id = t_gid[r < cnt2 ? r : base0];
+          const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(id - P.lo) * D) + p;
 #pragma unroll
-        for (int c = 0; c < L::C; c++) b[u][c] = load_row_chunk<true>(rp + c * L::LPR);
+          for (int c = 0; c < L::C; c++) b[u][c] = load_row_chunk<true>(rp + c * L::LPR);
+        }
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const int r = base0 + u * W * L::RPW + g;
-        const FT dist = row_reduce<D, ROW_SQDIFF>(a, b[u]);
-        if (r < cnt2 && p == 0) t_dist[t_slot[r]] = dist;
+        if (base0 + u * W * L::RPW < cnt2) {
+          const FT dist = row_reduce<D, ROW_SQDIFF>(a, b[u]);
+          if (r < cnt2 && p == 0) t_dist[t_slot[r]] = dist;
+        }
       }
     }
   } else if constexpr (D < 0 && !OcCode<D>::GEN) {
@@ -648,16 +659,20 @@ __device__ __forceinline__ u32 stage2_in_workgroup(const QParams &P, u32 x, int 
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const int r = base0 + u * W * rpw + g;
-        const u32 id = t_gid[(ol.valid && r < cnt2) ? r : base0];
-        const FT *rp = P.points + (size_t)(id - P.lo) * P.d;
+        if (base0 + u * W * rpw < cnt2) {  // wave-uniform
+          const u32 id = t_gid[(ol.valid && r < cnt2) ? r : base0];
+          const FT *rp = P.points + (size_t)(id - P.lo) * P.d;
 #pragma unroll
-        for (int c = 0; c < C; c++) b[u][c] = oc_load_chunk<D, OcCode<D>::NT_ROWS>(rp, p + c * oc, P.d);
+          for (int c = 0; c < C; c++) b[u][c] = oc_load_chunk<D, OcCode<D>::NT_ROWS>(rp, p + c * oc, P.d);
+        }
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const int r = base0 + u * W * rpw + g;
-        const FT dist = row_reduce_oc<C, ROW_SQDIFF, OC>(a, b[u], oc, p, oc_tree_len<D>(P.d));
-        if (ol.valid && r < cnt2 && p == 0) t_dist[t_slot[r]] = dist;
+        if (base0 + u * W * rpw < cnt2) {
+          const FT dist = row_reduce_oc<C, ROW_SQDIFF, OC>(a, b[u], oc, p, oc_tree_len<D>(P.d));
+          if (ol.valid && r < cnt2 && p == 0) t_dist[t_slot[r]] = dist;
+        }
       }
     }
   } else {
@@ -1399,18 +1414,25 @@ __global__ __launch_bounds__(256) void row_dists_kernel(QParams P, int Q, const 
                                                         FT *__restrict__ dist_out,
                                                         unsigned long long *__restrict__ rows_done,
                                                         const u32 *__restrict__ live_rows, u32 nrows,
-                                                        u32 chunk, u32 live_off) {
+                                                        u32 chunk, u32 live_off, u32 flat_split) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // Device-driven launches (live_rows != NULL) use a small persistent grid that walks the device-side row
   // count: launching one workgroup per POSSIBLE row just to exit cost ~50 us per launch at Q = 10k.
   // live_off: this launch covers entries [live_off, live_off + nrows) of the counted list (bounded workspace).
   if (live_rows) nrows = min(nrows, max(*live_rows, live_off) - live_off);
   const int lane = lane_id(), w = threadIdx.x >> 6, W = blockDim.x >> 6;
-  for (u32 row = blockIdx.x; row < nrows; row += gridDim.x) {
+  // flat_split > 0 (device-driven launches of long rows): a ONE-dimensional persistent grid over (row, part) items,
+  // part = which flat_split-th of the row's chunks -- a single flagged row still spreads over flat_split workgroups, a
+  // thousand of them keep the whole grid busy, and the launch that finds nothing to do is a few hundred workgroups.
+  const u32 nparts = flat_split ? flat_split : gridDim.y;
+  const u32 nitems = flat_split ? nrows * flat_split : nrows;
+  for (u32 item = blockIdx.x; item < nitems; item += gridDim.x) {
+  const u32 row = flat_split ? item / flat_split : item;
+  const u32 part = flat_split ? item % flat_split : blockIdx.y;
   const u32 x = qidx ? qidx[row] : xbase + row;
   if constexpr (MODE == MODE_GRAPH_DIST) {
     if (top_id[(size_t)x * P.k] == ANN_ID_FLAG) {  // workgroup-uniform
-      if (threadIdx.x == 0 && blockIdx.y == 0) ids_out[1 + atomicAdd(&ids_out[0], 1u)] = x;  // ids_out = {count, list...}
+      if (threadIdx.x == 0 && part == 0) ids_out[1 + atomicAdd(&ids_out[0], 1u)] = x;  // ids_out = {count, list...}
       continue;
     }
   }
@@ -1446,8 +1468,8 @@ __global__ __launch_bounds__(256) void row_dists_kernel(QParams P, int Q, const 
     for (int c = 0; c < OcCode<D>::C; c++) a[c] = oc_load_chunk<D, false>(y + (size_t)x * P.d, ol.p + c * ol.oc, P.d);
   }
   u32 gathered = 0;
-  // gridDim.y workgroups share one row: each takes every gridDim.y-th chunk of its slots
-  for (u32 c0 = blockIdx.y * chunk; c0 < len; c0 += gridDim.y * chunk) {
+  // nparts workgroups share one row: each takes every nparts-th chunk of its slots
+  for (u32 c0 = part * chunk; c0 < len; c0 += nparts * chunk) {
     const u32 c1 = min(len, c0 + chunk);
     if (threadIdx.x == 0) lcount[0] = 0;
     __syncthreads();
@@ -1488,23 +1510,27 @@ __global__ __launch_bounds__(256) void row_dists_kernel(QParams P, int Q, const 
     gathered += cnt;
     if constexpr (D > 0) {
       typedef RowLay<D> L;
-      constexpr int U = 8 / L::C;  // row passes in flight (see stage2_in_workgroup)
+      constexpr int U = (ANN_ROWS_INFLIGHT / L::C) > 0 ? (ANN_ROWS_INFLIGHT / L::C) : 1;  // row passes in flight (see stage2_in_workgroup)
       const int p = lane % L::LPR, g = lane / L::LPR;
       for (int base0 = w * L::RPW; base0 < cnt; base0 += W * L::RPW * U) {
         VT b[U][L::C];
 #pragma unroll
         for (int u = 0; u < U; u++) {
           const int r = base0 + u * W * L::RPW + g;
-          const u32 id = lid[r < cnt ? r : base0];
-          const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(id - P.lo) * D) + p;
+          if (base0 + u * W * L::RPW < cnt) {  // wave-uniform
+            const u32 id = lid[r < cnt ? r : base0];
+            const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(id - P.lo) * D) + p;
 #pragma unroll
-          for (int c = 0; c < L::C; c++) b[u][c] = load_row_chunk<true>(rp + c * L::LPR);
+            for (int c = 0; c < L::C; c++) b[u][c] = load_row_chunk<true>(rp + c * L::LPR);
+          }
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
           const int r = base0 + u * W * L::RPW + g;
-          const FT dist = row_reduce<D, ROW_SQDIFF>(a, b[u]);
-          if (r < cnt && p == 0) dist_row[lslot[r]] = dist;
+          if (base0 + u * W * L::RPW < cnt) {
+            const FT dist = row_reduce<D, ROW_SQDIFF>(a, b[u]);
+            if (r < cnt && p == 0) dist_row[lslot[r]] = dist;
+          }
         }
       }
     } else if constexpr (D < 0 && !OcCode<D>::GEN) {

@@ -345,7 +345,7 @@ __device__ inline bool tie_resolve(u32 L, int k, int K1, const u32 *__restrict__
   __syncthreads();
   {
     const u32 nwords = (P + 63u) >> 6, W = blockDim.x >> 6, w0 = threadIdx.x >> 6;
-    constexpr u32 UNR = 4;
+    constexpr u32 UNR = 16;  // loads in flight per lane: the 64 words of a 4 096-entry row in ONE round trip on four waves
     for (u32 ib = w0; ib < nwords; ib += W * UNR) {
       FT dbuf[UNR];
 #pragma unroll
