@@ -268,12 +268,16 @@ void annhip_synth_randnorm(size_t count, ftype *out);
 void annhip_synth_reset(void);
 
 /* ---- measurement ---------------------------------------------------------------------------------- */
-/* profile != 0: bracket every stage1 launch with HIP events on the index's stream. */
+/* profile = 1: bracket every stage-1 launch with HIP events on its stream, drop events at annhip_query's stage
+ * boundaries and count the gathered rows (one more small kernel per step).  profile = 2: the stage-1 event pair ONLY
+ * (two events per step; every event record costs ~5 us of stream time -- what bench.py keeps inside its timed region).
+ * 0: off. */
 void annhip_profile(annhip_index *ix, int profile);
 /* out[0]=stage-1 launches, out[1]=their total ms (events; only while profiling), out[2]=rows gathered in stage 1
- * (owned valid slots; only while profiling), out[3]=rows gathered in stage-2/exact rows kernels (only while
- * profiling), out[4]=queries through the exact path, out[5]=queries seen; counters accumulate since the last
- * reset (reset != 0 clears them after reading). */
+ * (owned valid slots; only with profile = 1), out[3]=rows gathered in stage-2/exact rows kernels (only with profile =
+ * 1), out[4]=queries flagged for the exact path, out[5]=queries seen, out[6]=of the flagged ones: answered by the tie
+ * path (ann_tie.h) instead of the literal network; counters accumulate since the last reset (reset != 0 clears them
+ * after reading). */
 void annhip_stats(annhip_index *ix, double out[8], int reset);
 /* While profiling, annhip_query also drops HIP events at its stage boundaries; out[0..5] = accumulated ms of
  * hash codes, stage-1 kernel, finalize + exact fallback, stage-2 rows, stage-2 network, id widening. */
