@@ -115,7 +115,7 @@ def load(prec="f32"):
     lib.annhip_stage1_rows.argtypes = [vp, sz, vp, C.c_int, u32p, u32p, sz, u32p, vp]
     lib.annhip_stage2_rows_list.argtypes = [vp, sz, vp, C.c_int, u32p, sz, u32p, vp, u32p, vp]
     lib.annhip_exact_select.argtypes = [vp, C.c_int, sz, u32p, vp, u32p, u32p, vp]
-    lib.annhip_test_sort_rows.argtypes = [sz, sz, sz, u32p, vp, vp, u32p, u32p, vp, vp]
+    lib.annhip_test_sort_rows.argtypes = [sz, sz, sz, u32p, vp, vp, u32p, u32p, vp, vp, C.c_int]
     lib.annhip_recall_ranks.argtypes = [sz, sz, sz, vp, sz, vp, vp, C.c_int, vp]
     lib.annhip_recall_ranks_host.argtypes = [sz, sz, sz, vp, sz, vp, vp, C.c_int, vp]
     lib.annhip_checksum_dev.restype = C.c_ulonglong

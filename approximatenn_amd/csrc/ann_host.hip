@@ -852,7 +852,7 @@ static void launch_rows(const QParams &P, size_t Q, const FT *y, int alias, cons
 static void launch_exact_select(u32 L, u32 len, u32 in_stride, int k, size_t nq, u32 *ids, FT *dist,
                                 const u32 *qidx, u32 xbase, u32 *out_i, FT *out_d, int ostride, int ooff,
                                 hipStream_t s, const u32 *live_rows = NULL, size_t *out64 = NULL, unsigned max_block = 1024,
-                                u32 live_off = 0, TieArgs tie = TieArgs{NULL, NULL, 0, NULL}) {
+                                u32 live_off = 0, TieArgs tie = TieArgs{NULL, NULL, 0, NULL, 0}) {
   if (!nq) return;
   const int lk = ann_lg(L);
   unsigned npairs = 8u << (lk > 4 ? lk - 4 : 0);
@@ -872,10 +872,13 @@ static void launch_exact_select(u32 L, u32 len, u32 in_stride, int k, size_t nq,
   const bool in_lds = row_smem <= env().lds_row_max;  // the whole row in LDS (a CU has 160 KB); longer rows sort in place in HBM
   const u32 Pn = (u32)1 << lk;
   int nw = 0;
-  if (tie.cand_d && env().tie && L >= 16 && tie.K1 == k + 1 && tie.K1 <= ANN_WAVE && (u32)k <= Pn)
+  if ((tie.cand_d || tie.derive) && env().tie && L >= 16 && tie.K1 == k + 1 && tie.K1 <= ANN_WAVE && (u32)k <= Pn)
     nw = Pn <= 4096 ? 1 : Pn <= 8192 ? 2 : Pn <= 16384 ? 4 : 0;
-  if (!nw) tie = TieArgs{NULL, NULL, 0, NULL};
-  const size_t smem = std::max(in_lds ? row_smem : (size_t)0, nw ? ann_tie_lds_bytes(nw) : (size_t)0);
+  size_t tie_smem = nw ? ann_tie_lds_bytes(nw) : 0;
+  if (nw && !tie.cand_d) tie_smem += ann_tie_derive_bytes(Pn);  // the list derived from the row: its keys live in LDS
+  if (tie_smem > 150 * 1024) nw = 0;
+  if (!nw) tie = TieArgs{NULL, NULL, 0, NULL, 0}, tie_smem = 0;
+  const size_t smem = std::max(in_lds ? row_smem : (size_t)0, tie_smem);
 #define CALL(LDS, NW)                                                                                                  \
   do {                                                                                                                 \
     allow_lds((exact_select_kernel<LDS, NW>), smem);                                                                   \
@@ -1004,7 +1007,7 @@ static long finalize_and_fallback(annhip_index *ix, const QParams &P, size_t Q, 
         launch_rows<MODE_TABLE>(P, Q, y, alias, codes, fl + p0, 0, nq, P.Lc1, NULL, NULL, ids, dist, rows_done, s, d_fcount,
                                 (u32)p0, qstride);
         launch_exact_select(P.L1, P.Lc1, P.Lc1, P.k, nq, ids, dist, fl + p0, 0, top_i, top_d, ostride, ooff, s, d_fcount,
-                            NULL, 1024, (u32)p0, TieArgs{cand_d, cand_i, K1, ix ? ix->d_rows + 3 : NULL});
+                            NULL, 1024, (u32)p0, TieArgs{cand_d, cand_i, K1, ix ? ix->d_rows + 3 : NULL, 0});
       }
       return -1;
     }
@@ -1028,7 +1031,7 @@ static long finalize_and_fallback(annhip_index *ix, const QParams &P, size_t Q, 
     const u32 *qidx = mode == 0 ? fl + q0 : NULL;
     launch_rows<MODE_TABLE>(P, Q, y, alias, codes, qidx, (u32)q0, nq, P.Lc1, NULL, NULL, ids, dist, rows_done, s, NULL, 0, qstride);
     launch_exact_select(P.L1, P.Lc1, P.Lc1, P.k, nq, ids, dist, qidx, (u32)q0, top_i, top_d, ostride, ooff, s, NULL, NULL, 1024,
-                        0, mode == 0 ? TieArgs{cand_d, cand_i, K1, ix ? ix->d_rows + 3 : NULL} : TieArgs{NULL, NULL, 0, NULL});
+                        0, mode == 0 ? TieArgs{cand_d, cand_i, K1, ix ? ix->d_rows + 3 : NULL, 0} : TieArgs{NULL, NULL, 0, NULL, 0});
   }
   return (long)nflag;
 }
@@ -1140,7 +1143,7 @@ static long query_impl(annhip_index *ix, annhip_workspace &ws, hipStream_t s, si
       FT *xd = (FT *)ws.xd.need(sizeof(FT) * Q * P.Lc1);
       launch_rows<MODE_TABLE>(P, Q, y, alias, codes, fl, 0, Q, P.Lc1, NULL, NULL, xi, xd, rows_ctr, s, ws.d_fcount);
       launch_exact_select(P.L1, P.Lc1, P.Lc1, k, Q, xi, xd, fl, 0, top_i, top_d, k, 0, s, ws.d_fcount, NULL, 1024, 0,
-                          TieArgs{cand_d, cand_i, K1, ix->d_rows + 3});
+                          TieArgs{cand_d, cand_i, K1, ix->d_rows + 3, 0});
       seg_mark(ix, marks, s);
       u32 *r2i = (u32 *)ws.r2i.need(sizeof(u32) * Q * P.Lc2);
       FT *r2d = (FT *)ws.r2d.need(sizeof(FT) * Q * P.Lc2);
@@ -1347,19 +1350,21 @@ extern "C" void annhip_exact_select(annhip_index *ix, int stage, size_t nq, uint
                                     const uint32_t *qidx_dev, uint32_t *out_id_dev, ftype *out_dist_dev) {
   const u32 L = stage == 1 ? ix->L1 : ix->L2, len = stage == 1 ? ix->Lc1 : ix->Lc2;
   launch_exact_select(L, len, len, (int)ix->k, nq, ids_dev, reinterpret_cast<FT *>(dist_dev), qidx_dev, 0,
-                      out_id_dev, reinterpret_cast<FT *>(out_dist_dev), (int)ix->k, 0, ix->stream);
+                      out_id_dev, reinterpret_cast<FT *>(out_dist_dev), (int)ix->k, 0, ix->stream, NULL, NULL, 1024, 0,
+                      TieArgs{NULL, NULL, (int)ix->k + 1, ix->d_rows + 3, 1});
 }
 
 // Test hook: sort_and_uniq on nq free-standing rows of reference length L (stride len = ann_need_len(L, k)), optionally
 // with the tie path fed by the candidate lists cand_*_dev [nq][k+1]; *resolved_dev counts the rows it answered.
 extern "C" void annhip_test_sort_rows(size_t L, size_t k, size_t nq, uint32_t *ids_dev, ftype *dist_dev,
                                       const ftype *cand_d_dev, const uint32_t *cand_i_dev, uint32_t *out_id_dev,
-                                      ftype *out_dist_dev, unsigned long long *resolved_dev) {
+                                      ftype *out_dist_dev, unsigned long long *resolved_dev, int derive) {
   gpu_init();
   const u32 len = (u32)ann_need_len(L, k);
   launch_exact_select((u32)L, len, len, (int)k, nq, ids_dev, reinterpret_cast<FT *>(dist_dev), NULL, 0, out_id_dev,
                       reinterpret_cast<FT *>(out_dist_dev), (int)k, 0, NULL, NULL, NULL, 1024, 0,
-                      TieArgs{reinterpret_cast<const FT *>(cand_d_dev), cand_i_dev, (int)k + 1, resolved_dev});
+                      TieArgs{reinterpret_cast<const FT *>(cand_d_dev), cand_i_dev, (int)k + 1, resolved_dev,
+                              cand_d_dev ? 0 : derive});
   HIPCHECK(hipStreamSynchronize(NULL));
 }
 
@@ -1453,9 +1458,11 @@ extern "C" void annhip_sh_exact1_end(annhip_index *ix, void *hip_stream, size_t 
                                      uint32_t *top_id_all_dev, ftype *top_dist_all_dev, uint32_t *top_id_dev,
                                      ftype *top_dist_dev) {
   hipStream_t s = (hipStream_t)hip_stream;
+  // (no rank but the owner ever held the merged candidate list of a flagged query: the tie path derives it from the
+  // reduced row)
   launch_exact_select(ix->L1, ix->Lc1, ix->Lc1, (int)ix->k, fcap, rows_id_dev, reinterpret_cast<FT *>(rows_dist_dev),
                       flist_dev + 2, 0, top_id_all_dev, reinterpret_cast<FT *>(top_dist_all_dev), (int)ix->k, 0, s, flist_dev,
-                      NULL, 256);
+                      NULL, 256, 0, TieArgs{NULL, NULL, (int)ix->k + 1, ix->d_rows + 3, 1});
   hipLaunchKernelGGL(patch_owner_kernel, dim3(8), dim3(256), 0, s, flist_dev, (u32)q_lo, (u32)qs, (int)ix->k, top_id_all_dev,
                      reinterpret_cast<const FT *>(top_dist_all_dev), top_id_dev, reinterpret_cast<FT *>(top_dist_dev));
   HIPCHECK(hipGetLastError());

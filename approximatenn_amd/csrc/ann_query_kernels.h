@@ -1577,6 +1577,7 @@ struct TieArgs {
   const u32 *cand_i;
   int K1;
   unsigned long long *resolved;  // statistics: rows answered by the tie path
+  int derive;         // cand_d == NULL: derive the list from the row itself (tie_derive_list)
 };
 template <bool USE_LDS, int NW>
 __global__ __launch_bounds__(1024) void exact_select_kernel(u32 L, u32 len, u32 in_stride, int k,
@@ -1594,10 +1595,18 @@ __global__ __launch_bounds__(1024) void exact_select_kernel(u32 L, u32 len, u32 
   u32 *gi = ids_in + (size_t)row * in_stride;
   FT *gd = dist_in + (size_t)row * in_stride;
   if constexpr (NW > 0) {
-    if (T.cand_d) {  // workgroup-uniform
+    if (T.cand_d || T.derive) {  // workgroup-uniform
       const size_t o = (size_t)x * ostride + ooff;
-      const bool done = tie_resolve<NW>(L, k, T.K1, gi, gd, T.cand_d + (size_t)x * T.K1, T.cand_i + (size_t)x * T.K1, smem,
-                                        out64 ? NULL : out_id + o, out64 ? out64 + o : NULL, out_dist + o, T.resolved);
+      const FT *cd = T.cand_d ? T.cand_d + (size_t)x * T.K1 : NULL;
+      const u32 *ci = T.cand_d ? T.cand_i + (size_t)x * T.K1 : NULL;
+      if (!T.cand_d && L >= 16 && T.K1 <= ANN_WAVE) {
+        FT *dcd;
+        u32 *dci;
+        tie_derive_list((u32)1 << ann_lg(L), T.K1, gi, gd, smem + ann_tie_lds_bytes(NW), &dcd, &dci);
+        cd = dcd, ci = dci;
+      }
+      const bool done = cd && tie_resolve<NW>(L, k, T.K1, gi, gd, cd, ci, smem,
+                                              out64 ? NULL : out_id + o, out64 ? out64 + o : NULL, out_dist + o, T.resolved);
       if (done) {
         if (threadIdx.x == 0 && T.resolved) atomicAdd(T.resolved, 1ull);
         continue;

@@ -41,6 +41,11 @@ __device__ __forceinline__ constexpr u64 tie_m() {
 __host__ __device__ inline size_t ann_tie_lds_bytes(int nw) {
   return 2 * sizeof(u64) * 64 * (size_t)nw + sizeof(u32) * (4 * ANN_TIE_MAX + ANN_TIE_BELOW + 8);
 }
+// ... and tie_derive_list in front of it (placed BEHIND tie_resolve's region): the valid keys of the sorted prefix, the
+// waves' partial lists (up to 16 waves), the list itself as distances + ids
+__host__ __device__ inline size_t ann_tie_derive_bytes(size_t P) {
+  return sizeof(Key) * (P + 17 * (size_t)ANN_WAVE) + (sizeof(FT) + sizeof(u32)) * ANN_WAVE + 128;
+}
 
 // exchange neighbouring blocks of 2^T bits
 template <int T>
@@ -184,6 +189,57 @@ __device__ __forceinline__ void tie_net_sim(int lk, u64 (&AB)[NW], u64 (&NB)[NW]
     for (int ss = s; ss >= 6; ss--) tie_cross<NW>(s, ss, AB, NB, tracked, pos);
     tie_sub<NW, 6, 5>(AB, NB, tracked, pos);  // strides 32 .. 1, straight
   }
+}
+
+// The candidate list of a row from the row itself -- for callers that have no stage-1 list of the row's query (a sharded
+// host's reduced rows: only the query's owner ever held the merged list; stage-2 rows; the staged API): the K1 smallest
+// DISTINCT (distance, id) keys among the finite entries of the row's first P slots, ascending, as cd / ci in LDS, padded
+// with (+inf, ANN_ID_NONE).  One workgroup: all waves compact the finite keys into LDS, every wave selects the K1
+// smallest of its share (wave_select_smallest), wave 0 merges.  `lds`: ann_tie_derive_bytes(P) bytes.
+__device__ inline void tie_derive_list(u32 P, int K1, const u32 *__restrict__ gi, const FT *__restrict__ gd,
+                                       unsigned char *lds, FT **cd_out, u32 **ci_out) {
+  const int lane = lane_id(), w = threadIdx.x >> 6, W = blockDim.x >> 6;
+  Key *keys = reinterpret_cast<Key *>(lds);
+  Key *part = keys + P;                    // [W][K1], K1 <= 64, W <= 16
+  Key *fin = part + 16 * ANN_WAVE;         // [K1]
+  FT *cd = reinterpret_cast<FT *>(fin + ANN_WAVE);
+  u32 *ci = reinterpret_cast<u32 *>(cd + ANN_WAVE);
+  u32 *cnt = ci + ANN_WAVE;                // [0] keys [1..W] the waves' list lengths
+  if (threadIdx.x < 20) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  for (u32 j0 = (u32)w * ANN_WAVE; j0 < P; j0 += (u32)W * ANN_WAVE) {
+    const u32 j = j0 + lane;
+    const FT dj = j < P ? gd[j] : ft_inf();
+    const bool ok = dj < ft_inf();
+    const u64 m = __ballot(ok);
+    if (m) {
+      u32 base = 0;
+      if (lane == 0) base = atomicAdd(&cnt[0], (u32)__popcll(m));
+      base = __shfl(base, 0);
+      if (ok) keys[base + mask_rank(m)] = key_make(dj, gi[j]);
+    }
+  }
+  __syncthreads();
+  const int n = (int)cnt[0], per = (n + W - 1) / W, a = min(n, w * per), b = min(n, a + per);
+  const int mw = wave_select_smallest(keys + a, b - a, K1, part + (size_t)w * ANN_WAVE);
+  if (lane == 0) cnt[1 + w] = (u32)mw;
+  __syncthreads();
+  if (w == 0) {
+    int tot = 0;  // the partial lists, packed into the (now free) front of `keys`
+    for (int ww = 0; ww < W; ww++) {
+      const int mm = (int)cnt[1 + ww];
+      for (int i = lane; i < mm; i += ANN_WAVE) keys[tot + i] = part[(size_t)ww * ANN_WAVE + i];
+      tot += mm;
+    }
+    wave_lds_sync();
+    const int m = wave_select_smallest(keys, tot, K1, fin);
+    for (int t = lane; t < ANN_WAVE; t += ANN_WAVE) {
+      cd[t] = t < m ? key_dist(fin[t]) : ft_inf();
+      ci[t] = t < m ? key_id(fin[t]) : ANN_ID_NONE;
+    }
+  }
+  __syncthreads();
+  *cd_out = cd, *ci_out = ci;
 }
 
 // Wave 0's part of tie_resolve (below): LDS holds the class bits LA/LB, the tied positions, the positions below v and

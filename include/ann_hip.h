@@ -235,10 +235,11 @@ void annhip_exact_select(annhip_index *ix, int stage, size_t nq, uint32_t *ids_d
 /* Test hook: sort_and_uniq (alg.c:224-230) on nq free-standing rows of reference length L (row stride
  * min(L, max(2^floor(log2 L), k) + 1)); with cand_d_dev / cand_i_dev [nq][k+1] (the k+1 smallest distinct keys of each
  * row's sorted prefix, ascending, padded with (+inf, 0xFFFFFFFF)) rows with a single run of tied distances are answered
- * by the tie path instead of the network; *resolved_dev (device counter, may be NULL) counts them.  Synchronous. */
+ * by the tie path instead of the network; *resolved_dev (device counter, may be NULL) counts them.  derive != 0 with
+ * cand_d_dev == NULL: the kernel derives those lists from the rows itself (what sharded hosts use).  Synchronous. */
 void annhip_test_sort_rows(size_t L, size_t k, size_t nq, uint32_t *ids_dev, ftype *dist_dev, const ftype *cand_d_dev,
                            const uint32_t *cand_i_dev, uint32_t *out_id_dev, ftype *out_dist_dev,
-                           unsigned long long *resolved_dev);
+                           unsigned long long *resolved_dev, int derive);
 
 /* ---- content checksums (device memory in, 64-bit value out; synchronous) ------------------------------------------- */
 /* annhip_checksum_dev: checksum of nbytes of device memory (4-byte aligned), independent of the launch geometry.

@@ -57,7 +57,7 @@ def _rows(rng, L, k, nq, n, ft, groups):
     return ids, dist, cand_d, cand_i
 
 
-def _sort_rows(lib, L, k, ids, dist, cand_d, cand_i, use_tie):
+def _sort_rows(lib, L, k, ids, dist, cand_d, cand_i, use_tie, derive=0):
     nq = ids.shape[0]
     ti, td = torch.from_numpy(ids.copy()).cuda(), torch.from_numpy(dist.copy()).cuda()
     oi = torch.zeros((nq, k), dtype=torch.int32, device="cuda")
@@ -66,7 +66,7 @@ def _sort_rows(lib, L, k, ids, dist, cand_d, cand_i, use_tie):
     cd, ci = torch.from_numpy(cand_d).cuda(), torch.from_numpy(cand_i.view(np.int32)).cuda()
     torch.cuda.synchronize()
     lib.annhip_test_sort_rows(L, k, nq, ti.data_ptr(), td.data_ptr(), cd.data_ptr() if use_tie else None,
-                              ci.data_ptr() if use_tie else None, oi.data_ptr(), od.data_ptr(), cnt.data_ptr())
+                              ci.data_ptr() if use_tie else None, oi.data_ptr(), od.data_ptr(), cnt.data_ptr(), derive)
     torch.cuda.synchronize()
     return oi.cpu().numpy().view(np.uint32), od.cpu().numpy(), int(cnt.item())
 
@@ -86,10 +86,17 @@ def test_tie_rows_match_the_network(prec, L, k):
     li, ld, _ = _sort_rows(lib, L, k, ids, dist, cand_d, cand_i, False)
     gi, gd, resolved = _sort_rows(lib, L, k, ids, dist, cand_d, cand_i, True)
     assert np.array_equal(gi, li) and bits_equal(gd, ld)
+    # ... and with the candidate lists derived from the rows by the kernel itself (sharded hosts, staged API)
+    di, dd_, resolved_d = _sort_rows(lib, L, k, ids, dist, cand_d, cand_i, False, derive=1)
+    assert np.array_equal(di, li) and bits_equal(dd_, ld)
     if L <= 16384 + 16383:
         assert resolved >= nq // 16, resolved
+        # (the derived list's keys live in LDS: 16 B each in double -- 8 192 of them plus the tie path's own state
+        # exceed a CU's LDS, as do 16 384 in float: those rows take the network)
+        too_big = L >= (8192 if prec == "f64" else 16384)
+        assert resolved_d == (0 if too_big else resolved), (resolved_d, resolved)
     else:
-        assert resolved == 0
+        assert resolved == 0 and resolved_d == 0
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])

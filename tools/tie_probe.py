@@ -29,7 +29,7 @@ keys = sorted(set((float(dist[0, j]), int(ids[0, j])) for j in range(P) if np.is
 cand_d = np.array([[a for a, b in keys]], ft)
 cand_i = np.array([[b for a, b in keys]], np.uint32)
 out = {}
-for use in (0, 1):
+for use in (0, 1, 2):  # the network / tie path with the given list / tie path with the list derived from the row
     oi = torch.zeros((1, k), dtype=torch.int32, device="cuda")
     od = torch.zeros((1, k), dtype=torch.float32 if prec == "f32" else torch.float64, device="cuda")
     cnt = torch.zeros(16, dtype=torch.int64, device="cuda")
@@ -37,8 +37,8 @@ for use in (0, 1):
     for it in range(20):
         ti, td = torch.from_numpy(ids.copy()).cuda(), torch.from_numpy(dist.copy()).cuda()
         torch.cuda.synchronize()
-        lib.annhip_test_sort_rows(L, k, 1, ti.data_ptr(), td.data_ptr(), cd.data_ptr() if use else None,
-                                  ci.data_ptr() if use else None, oi.data_ptr(), od.data_ptr(), cnt.data_ptr())
+        lib.annhip_test_sort_rows(L, k, 1, ti.data_ptr(), td.data_ptr(), cd.data_ptr() if use == 1 else None,
+                                  ci.data_ptr() if use == 1 else None, oi.data_ptr(), od.data_ptr(), cnt.data_ptr(), 1 if use == 2 else 0)
     torch.cuda.synchronize()
     out[use] = (oi.cpu().numpy().copy(), od.cpu().numpy().copy(), int(cnt[0].item()))
     if use and os.environ.get("ANN_TIE_TS"):
@@ -46,4 +46,5 @@ for use in (0, 1):
         print("phase timestamps (us since entry): list %.1f scan %.1f counts %.1f sort1 %.1f rdups %.1f sort2 %.1f out %.1f"
               % tuple((ts[i] - ts[0]) / 100.0 for i in range(1, 8)))
 assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
-print("L=%d %s: same result; rows answered by the tie path: %d of 20" % (L, prec, out[1][2]))
+assert np.array_equal(out[0][0], out[2][0]) and np.array_equal(out[0][1], out[2][1])
+print("L=%d %s: same result; rows answered by the tie path: %d of 20 (list given), %d of 20 (list derived)" % (L, prec, out[1][2], out[2][2]))
