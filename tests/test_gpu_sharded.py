@@ -67,6 +67,9 @@ class ThreadDist:
         self._done()
 
 
+LAST_TIE_QUERIES = {}
+
+
 def _run_sharded(prec, save_arrays, pts, y, world, alias=False, fast=True, pipelined=False, schedule=None):
     save = A.Save.from_dict(prec, save_arrays)
     td = ThreadDist(world)
@@ -94,6 +97,7 @@ def _run_sharded(prec, save_arrays, pts, y, world, alias=False, fast=True, pipel
                 ids, dd = sq.query(yt, alias=alias)
             torch.cuda.synchronize()
             results[rank] = (ids.cpu().numpy().astype(np.uint64), dd.cpu().numpy(), sq.last_exact)
+            LAST_TIE_QUERIES[rank] = ix.stats()["tie_queries"]  # flagged rows this rank answered without the network
             ix.close()
         except Exception as e:  # noqa: BLE001
             errors.append(e)

@@ -168,3 +168,30 @@ def test_queries_with_a_few_duplicated_points(prec, d, k, T, fuse, monkeypatch):
         A._lib.reload_env()
         A._lib.load(prec).annhip_cache_clear()
         save.free()
+
+
+@pytest.mark.parametrize("prec,world", [("f32", 2), ("f64", 3)])
+def test_sharded_exact_step_uses_the_tie_path(prec, world):
+    """Rows sharded over thread ranks of one GPU: the flagged queries' rows are reduced across the ranks and EVERY rank
+    answers them -- from a candidate list it derives from the reduced row (only the owner ever held the merged one).
+    Same answers as the oracle, and the ranks' statistics show rows answered by the tie path."""
+    from tests import test_gpu_sharded as TS
+    d, k, T, n, Q = 64, 10, 6, 6000, 400
+    orc = O.CpuBackend(prec, "oracle")
+    O.srandom(99)
+    orc.rand_norm_reset()
+    pts = orc.gen_rand(n * d).reshape(n, d)
+    y = orc.gen_rand(Q * d).reshape(Q, d)
+    rng = np.random.default_rng(3)
+    src = rng.choice(n, size=n // 50, replace=False)
+    dst = rng.choice(np.setdiff1d(np.arange(n), src), size=src.size, replace=False)
+    pts[dst] = pts[src]
+    y[:100] = pts[src[:100]] + (0.01 * orc.gen_rand(100 * d).reshape(100, d)).astype(pts.dtype)
+    pts, y = np.ascontiguousarray(pts), np.ascontiguousarray(y)
+    O.srandom(11)
+    _, _, o_save = orc.precomp(pts, k, T)
+    want = orc.query(o_save, pts, y)
+    TS.LAST_TIE_QUERIES.clear()
+    for s_ids, s_d, s_ex in TS._run_sharded(prec, o_save, pts, y, world):
+        assert np.array_equal(s_ids, want[0]) and bits_equal(s_d, want[1]) and s_ex > 0
+    assert len(TS.LAST_TIE_QUERIES) == world and all(v > 0 for v in TS.LAST_TIE_QUERIES.values()), TS.LAST_TIE_QUERIES
