@@ -77,6 +77,7 @@ struct EnvCfg {
   int cache_mode = 0;  // ANN_HIP_CACHE: 0 sampled fingerprint (default), 1 strict (full content hash), 2 off
   size_t bk_group = 0;  // ANN_HIP_BK_GROUP: cap on the members per pass of precomp's bucket kernel (0 = what fits the LDS)
   int fin_tail = 1;     // ANN_HIP_FIN_TAIL: 0 = finalize1 as its own launch after stage 1 (A/B; default: in the stage-1 workgroups' tail)
+  int s2_multi = 1;     // ANN_HIP_S2_MULTI: 0 = sharded stage-2 distances with one workgroup per query (A/B of stage2_dist_multi_kernel)
   int codes_lpq = 1;    // ANN_HIP_CODES_LPQ: 0 = the lanes-per-row hash kernel for every row length (A/B)
   int tie = 1;          // ANN_HIP_TIE: 0 = flagged rows always take the literal network (no tie path, ann_tie.h)
 };
@@ -109,6 +110,7 @@ static void load_env() {
   c.bk_group = env_size("ANN_HIP_BK_GROUP", 0);
   c.tie = env_int("ANN_HIP_TIE", 1);
   c.codes_lpq = env_int("ANN_HIP_CODES_LPQ", 1);
+  c.s2_multi = env_int("ANN_HIP_S2_MULTI", 1);
   c.fin_tail = env_int("ANN_HIP_FIN_TAIL", 1);
   const char *cm = getenv("ANN_HIP_CACHE");
   c.cache_mode = !cm ? 0 : !strcmp(cm, "strict") ? 1 : !strcmp(cm, "off") ? 2 : 0;
@@ -616,6 +618,14 @@ static void launch_codes_lpq_d(const QParams &P, size_t Q, const FT *y, u32 *cod
     allow_lds(codes_lpq_kernel<DD>, smem);
     hipLaunchKernelGGL(codes_lpq_kernel<DD>, grid, dim3(64), smem, s, P, (int)Q, y, codes, zero_me);
   }
+}
+
+template <int DD>
+static void launch_s2_multi_d(const QParams &P, size_t Q, const FT *y, int alias, u32 qpb, unsigned grid, const u32 *top_all,
+                              FT *dist_out, u32 *flagged, unsigned long long *rows_ctr, hipStream_t s) {
+  if constexpr (DD > 0)
+    hipLaunchKernelGGL(stage2_dist_multi_kernel<DD>, dim3(grid), dim3(256), 0, s, P, (int)Q, y, alias, P.Lc2, qpb, top_all,
+                       dist_out, flagged, rows_ctr);
 }
 
 // Qhash <= Q: only the first Qhash queries are hashed.  Stage 1 reads code[i*Q + x] for the tries i that own a
@@ -1474,6 +1484,20 @@ extern "C" void annhip_sh_stage2(annhip_index *ix, void *hip_stream, size_t Q, c
   const QParams P = make_params(ix);
   hipStream_t s = (hipStream_t)hip_stream;
   zero_u32_kernel<<<1, 1, 0, s>>>(flagged_dev);  // flagged_dev = {count, query indices...}, Q + 1 entries
+  const u32 per = P.Lc2 - (u32)P.k;
+  if (d_is_fast(P.d) && env().s2_multi && per && per <= ANN_S2M_CAP && Q) {  // many queries per workgroup (stage2_dist_multi_kernel)
+    // queries per workgroup: enough to fill the gather loop (a rank owns (hi - lo) / n of the slots), within the LDS lists
+    const double own = std::max(1e-3, (double)(P.hi - P.lo) / (double)P.n);
+    u32 qpb = (u32)std::min<double>(64.0, std::max(1.0, 128.0 / (own * per)));
+    qpb = std::max<u32>(1, std::min<u32>(qpb, ANN_S2M_CAP / per));
+    const unsigned grid = (unsigned)((Q + qpb - 1) / qpb);
+#define CALL(DD) launch_s2_multi_d<DD>(P, Q, reinterpret_cast<const FT *>(y_dev), alias, qpb, grid, top_id_all_dev, \
+                                       reinterpret_cast<FT *>(dist_out_dev), flagged_dev, ix->profile == 1 ? ix->d_rows + 8 : NULL, s)
+    ANN_DISPATCH_D2(P.d, CALL);
+#undef CALL
+    HIPCHECK(hipGetLastError());
+    return;
+  }
   launch_rows<MODE_GRAPH_DIST>(P, Q, reinterpret_cast<const FT *>(y_dev), alias, NULL, NULL, 0, Q, P.Lc2, top_id_all_dev,
                                NULL, flagged_dev, reinterpret_cast<FT *>(dist_out_dev), ix->profile == 1 ? ix->d_rows + 8 : NULL, s);
 }

@@ -1565,6 +1565,76 @@ __global__ __launch_bounds__(256) void row_dists_kernel(QParams P, int Q, const 
   }
 }
 
+// ------------------------------------------------------------------------------- stage2_dist_multi
+// row_dists<MODE_GRAPH_DIST> for many queries per workgroup (sharded hosts, power-of-two d).  One workgroup per
+// query is mostly overhead there: a rank owns 1/G of the rows, i.e. ~7 of a cfg3 query's 55 stage-2 slots at G = 8,
+// behind three dependent round trips (top ids -> graph row -> point rows) -- 80k workgroups, 0.10 ms for 47 us worth of
+// rows.  Here a 256-thread workgroup takes QPB queries: their (len - k) * QPB slots are derived side by side (the
+// loads of different queries are independent), the owned ones of ALL of them go through one gather loop.
+// Same outputs as row_dists<MODE_GRAPH_DIST>: dist_out[x][len - k] (+inf for slots this device does not own, sentinels,
+// the excluded self row), flagged queries skipped and appended to flagged = {count, list...}.
+#define ANN_S2M_CAP 2048  // slots per workgroup (LDS lists)
+template <int D>
+__global__ __launch_bounds__(256) void stage2_dist_multi_kernel(QParams P, int Q, const FT *__restrict__ y, int alias,
+                                                                u32 len, u32 qpb, const u32 *__restrict__ top_id,
+                                                                FT *__restrict__ dist_out, u32 *__restrict__ flagged,
+                                                                unsigned long long *__restrict__ rows_done) {
+  static_assert(D > 0, "power-of-two row layout only");
+  typedef RowLay<D> L;
+  __shared__ u32 lq[ANN_S2M_CAP], lslot[ANN_S2M_CAP], lid[ANN_S2M_CAP];  // owned slots: local query, slot, point id
+  __shared__ u32 lcount;
+  const int lane = lane_id(), w = threadIdx.x >> 6, W = blockDim.x >> 6;
+  const u32 k = (u32)P.k, per = len - k;
+  const u32 x0 = blockIdx.x * qpb, nq = min(qpb, (u32)Q - x0);
+  if (threadIdx.x == 0) lcount = 0;
+  __syncthreads();
+  for (u32 e = threadIdx.x; e < nq * per; e += blockDim.x) {
+    const u32 ql = e / per, j = k + (e - ql * per), x = x0 + ql;
+    const u32 first = top_id[(size_t)x * k];
+    if (first == ANN_ID_FLAG) {  // the exact path redoes this query: listed once, no distances
+      if (j == k) flagged[1 + atomicAdd(&flagged[0], 1u)] = x;
+      continue;
+    }
+    const u32 parent = top_id[(size_t)x * k + (j / k - 1)];
+    const u32 z = j % k;
+    const u32 id = parent < P.n ? P.graph[(size_t)parent * k + z] : (P.graph[z] | P.n);  // supercharge, Q7
+    const bool own = id < P.n && !(alias && id == x) && id >= P.lo && id < P.hi;
+    if (own) {
+      const u32 pos = atomicAdd(&lcount, 1u);
+      lq[pos] = ql, lslot[pos] = j - k, lid[pos] = id;
+    } else {
+      dist_out[(size_t)x * per + (j - k)] = ft_inf();
+    }
+  }
+  __syncthreads();
+  const int cnt = (int)lcount;
+  const int p = lane % L::LPR, g = lane / L::LPR;
+  constexpr int U = (4 / L::C) > 0 ? (4 / L::C) : 1;  // row passes in flight
+  for (int base0 = w * L::RPW; base0 < cnt; base0 += W * L::RPW * U) {
+    VT a[U][L::C], b[U][L::C];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int r = base0 + u * W * L::RPW + g;
+      if (base0 + u * W * L::RPW < cnt) {  // wave-uniform
+        const int rr = r < cnt ? r : base0;
+        const VT *yp = reinterpret_cast<const VT *>(y + (size_t)(x0 + lq[rr]) * D) + p;
+        const VT *rp = reinterpret_cast<const VT *>(P.points + (size_t)(lid[rr] - P.lo) * D) + p;
+#pragma unroll
+        for (int c = 0; c < L::C; c++) a[u][c] = yp[c * L::LPR], b[u][c] = load_row_chunk<true>(rp + c * L::LPR);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int r = base0 + u * W * L::RPW + g;
+      if (base0 + u * W * L::RPW < cnt) {
+        const FT dist = row_reduce<D, ROW_SQDIFF>(a[u], b[u]);
+        if (r < cnt && p == 0) dist_out[(size_t)(x0 + lq[r]) * per + lslot[r]] = dist;
+      }
+    }
+  }
+  if (rows_done && threadIdx.x == 0) atomicAdd(&rows_done[(blockIdx.x & 63u) * 8u], (unsigned long long)cnt);
+}
+
 // ----------------------------------------------------------------------------------- exact_select
 // sort_and_uniq (alg.c:224-230) on `len` stored entries of a row of reference length L, then the first k
 // entries out.  One workgroup per row.  USE_LDS: the row is staged in LDS, otherwise the network runs in
