@@ -1,4 +1,14 @@
-import numpy as np, random
+"""The tie path of approximatenn_amd/csrc/ann_tie.h in plain Python, beside a literal model of the reference's
+sort_and_uniq (/root/reference/alg.c:224-230: do_sort, rdups, do_sort; network of compute.cl:188-203, strict `>`).
+
+literal(L, length, key, ids, k)        the network on (key, id) pairs, kill the first of adjacent equal ids, network; first k
+tie_path(L, length, key, ids, k, n)    the same answer WITHOUT sorting, for rows whose k+1 smallest distinct keys hold one run
+                                       of equal distances: class bits (below / tied / above the tied distance) pushed through
+                                       the comparator sequence, the tied entries following their partners' classes.  None when
+                                       the row does not qualify (the kernel then runs the network).
+`python tools/tie_model.py` checks tie_path against literal on 20 000 random rows; tests/test_tie_model.py runs a shorter
+version of that in the CPU suite, tests/test_gpu_tie.py compares the kernel with both."""
+import random
 INF=float('inf')
 def lg(x):
     r=0
@@ -91,28 +101,35 @@ def tie_path(L,length,key,ids,k,n):
         else:
             u=t1+1+(t-t0-st); oi.append(ks[u][1]);od.append(ks[u][0])
     return oi,od
-random.seed(1)
-tot=0;hit=0
-for it in range(20000):
-    L=random.choice([16,17,24,32,40,64,100,128,200,256])
-    P=1<<lg(L); k=random.choice([1,2,3,5,10])
-    length=min(L,max(P,k)+1)
-    n=1000
-    npts=random.choice([5,10,30,100])
-    pts=random.sample(range(n),npts)
-    dist={p:float(random.randint(1,1000)) for p in pts}
-    # make a tie group
-    g=random.sample(pts,random.choice([2,2,2,3,4]))
-    for p in g: dist[p]=dist[g[0]]
-    ids=[]
-    for j in range(length):
-        if random.random()<0.4: ids.append(n)
-        else: ids.append(random.choice(pts))
-    key=[dist[i] if i<n else INF for i in ids]
-    r=tie_path(L,length,key,ids,k,n)
-    tot+=1
-    if r is None: continue
-    hit+=1
-    li,ld=literal(L,length,key,ids,k)
-    assert (li,ld)==(r[0],r[1]),(L,k,li,ld,r)
-print(tot,hit)
+
+
+def self_check(rows=20000, seed=1):
+    """tie_path == literal on random rows with forced ties; returns (rows tried, rows the tie path answered)."""
+    random.seed(seed)
+    tot = hit = 0
+    for it in range(rows):
+        L = random.choice([16, 17, 24, 32, 40, 64, 100, 128, 200, 256])
+        P = 1 << lg(L)
+        k = random.choice([1, 2, 3, 5, 10])
+        length = min(L, max(P, k) + 1)
+        n = 1000
+        npts = random.choice([5, 10, 30, 100])
+        pts = random.sample(range(n), npts)
+        dist = {p: float(random.randint(1, 1000)) for p in pts}
+        g = random.sample(pts, random.choice([2, 2, 2, 3, 4]))
+        for p in g:
+            dist[p] = dist[g[0]]
+        ids = [n if random.random() < 0.4 else random.choice(pts) for _ in range(length)]
+        key = [dist[i] if i < n else INF for i in ids]
+        r = tie_path(L, length, key, ids, k, n)
+        tot += 1
+        if r is None:
+            continue
+        hit += 1
+        li, ld = literal(L, length, key, ids, k)
+        assert (li, ld) == (r[0], r[1]), (L, k, li, ld, r)
+    return tot, hit
+
+
+if __name__ == "__main__":
+    print("%d rows, %d answered by the tie path, all equal to the literal network" % self_check())
