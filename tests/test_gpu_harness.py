@@ -28,6 +28,18 @@ def test_compare_results_query_mode(prec):
     assert "Average diffs for query: 0" in out and "PASS" in out and "0 not bit-identical" in out
 
 
+@pytest.mark.parametrize("pieces", ["1", "3", "8"])
+def test_query_gpu_batch_sent_in_pieces(pieces):
+    """query_gpu on a batch large enough to be sent in pieces (>= 1 MB each): the pieces cross PCIe on a stream of their
+    own while the main stream hashes the ones that have arrived (events between the two); ragged last piece.  A fresh
+    process per setting: ANN_HIP_IO_PIECES is read once."""
+    env = dict(os.environ, ANN_HIP_IO_PIECES=pieces)
+    out = subprocess.run([os.path.join(H, "compare_results_f32"), "-n", "20000", "-d", "128", "-y", "16391", "-o", "2", "-S", "43"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "Average diffs for query: 0" in out.stdout and "PASS" in out.stdout and "0 not bit-identical" in out.stdout
+
+
 def test_time_results_runs_config1_shape():
     out = _run([os.path.join(H, "time_results_f32"), "-n", "20000", "-d", "32", "-k", "10", "-y", "500", "-o", "3", "-S", "7"])
     assert "queries/s" in out and "on CPU, oracle" in out
