@@ -280,8 +280,6 @@ struct annhip_index {
   annhip_workspace ws;           // default workspace (annhip_query, staged calls)
   DevBuf io_y, io_ids, io_dist;  // query_gpu's staging of host inputs/outputs, reused between calls
   PinBuf io_y_pin, io_out_pin;   // ... and their pinned host-side bounce buffers
-  hipStream_t io_copy_stream = NULL;      // query_gpu: the batch's pieces cross PCIe on this stream while the main stream hashes
-  std::vector<hipEvent_t> io_ev;          // ... one event per piece
   unsigned long long *d_rows = NULL;  // [0] stage-1 gathered rows, [2] exact-path queries, [3] of those: answered by the tie path, [8..8+512) rows kernels (64 padded shards)
   // measurement
   int profile = 0;  // 1: stage-1 event pair + stage marks + row statistics; 2: the stage-1 event pair only (two events per
@@ -474,8 +472,6 @@ extern "C" void annhip_index_destroy(annhip_index *ix) {
   ix->ws.release();
   ix->io_y.release(), ix->io_ids.release(), ix->io_dist.release();
   ix->io_y_pin.release(), ix->io_out_pin.release();
-  for (hipEvent_t e : ix->io_ev) (void)hipEventDestroy(e);
-  if (ix->io_copy_stream) (void)hipStreamDestroy(ix->io_copy_stream);
   for (auto &e : ix->ev_used) (void)hipEventDestroy(e.a), (void)hipEventDestroy(e.b);
   for (auto &e : ix->ev_free) (void)hipEventDestroy(e.a), (void)hipEventDestroy(e.b);
   for (hipEvent_t e : ix->seg_free) (void)hipEventDestroy(e);
@@ -2452,18 +2448,13 @@ static void query_single_begin(annhip_index *ix, size_t ycnt, const ftype *y, in
   const size_t per = (ycnt + pieces - 1) / pieces;
   u32 *codes = (u32 *)ix->ws.codes.need(sizeof(u32) * ycnt * P.T);
   if (!ix->ws.d_fcount) ix->ws.d_fcount = dev_alloc<u32>(4);
-  // The pieces cross PCIe back to back on a stream of their own; the main stream hashes piece i (an event away) while
-  // piece i+1 is on the wire -- only the last piece's hash is left in front of stage 1 (which needs every code, Q2).
-  // (created only when a batch is large enough to be sent in pieces: a process has four hardware queues by default, and a
-  // fifth stream shares one with somebody -- the mere existence of this stream took a three-lane annhip_stream pipeline
-  // of 1k-query batches from 51 to 72 us per batch)
-  if (pieces > 1 && !ix->io_copy_stream) HIPCHECK(hipStreamCreateWithFlags(&ix->io_copy_stream, hipStreamNonBlocking));
-  while (pieces > 1 && ix->io_ev.size() < pieces) {
-    hipEvent_t e;
-    HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    ix->io_ev.push_back(e);
-  }
-  hipStream_t cs = pieces > 1 ? ix->io_copy_stream : s;
+  // Everything of the call runs on ONE stream: the pieces' copy kernels back to back (PCIe stays busy while the host
+  // threads copy the next piece into pinned memory), one hash launch, the step.  A copy stream of its own with the
+  // hashes on the main stream an event away was built and measured: a cross-stream event wait takes ~40 us to take
+  // effect -- longer than the 28 us of hashing it was meant to hide (stage 1 started 193-204 us into the call either
+  // way) -- and a process has only four hardware queues: the extra stream serialised an annhip_stream pipeline of small
+  // batches (51 -> 72 us per batch).
+  hipStream_t cs = s;
   std::vector<std::atomic<int>> copied(pieces);
   for (auto &c : copied) c.store(0, std::memory_order_relaxed);
   // every piece is itself copied by several pool threads: items = pieces x lanes, taken in order
@@ -2476,23 +2467,21 @@ static void query_single_begin(annhip_index *ix, size_t ycnt, const ftype *y, in
     copied[i].fetch_add(1, std::memory_order_release);
   };
   HostPool::get().begin(pieces * lanes, copy_part);
+  // ONE hash launch behind the last piece (stage 1 reads the codes of the first `hashed` queries only, Q1/Q2)
   bool zeroed = false;
   for (size_t i = 0; i < pieces; i++) {
     const size_t q0 = i * per, nq = q0 < ycnt ? std::min(per, ycnt - q0) : 0;
     while ((size_t)copied[i].load(std::memory_order_acquire) < lanes) {
     }
-    if (!nq) continue;
-    const size_t bytes = nq * row;  // rows are multiples of 4 bytes at least; the tail handles what is not 16
-    copy_in_kernel<<<grid_for(bytes / 16 ? bytes / 16 : 1, 256, 512), 256, 0, cs>>>(
-        bytes / 16, reinterpret_cast<const copy_vec4 *>(y_pin_dev + q0 * row), reinterpret_cast<copy_vec4 *>((char *)y_dev + q0 * row),
-        bytes % 16, bytes);
-    if (cs != s) {
-      HIPCHECK(hipEventRecord(ix->io_ev[i], cs));
-      HIPCHECK(hipStreamWaitEvent(s, ix->io_ev[i], 0));
+    if (nq) {
+      const size_t bytes = nq * row;  // rows are multiples of 4 bytes at least; the tail handles what is not 16
+      copy_in_kernel<<<grid_for(bytes / 16 ? bytes / 16 : 1, 256, 512), 256, 0, cs>>>(
+          bytes / 16, reinterpret_cast<const copy_vec4 *>(y_pin_dev + q0 * row), reinterpret_cast<copy_vec4 *>((char *)y_dev + q0 * row),
+          bytes % 16, bytes);
     }
-    if (q0 < hashed) {
-      launch_codes(P, std::min(nq, hashed - q0), y_dev + q0 * d, codes + q0 * P.T, s, zeroed ? NULL : ix->ws.d_fcount);
-      zeroed = true;
+    if (i + 1 == pieces) {
+      launch_codes(P, hashed, y_dev, codes, s, ix->ws.d_fcount);
+      zeroed = hashed > 0;
     }
   }
   HIPCHECK(hipGetLastError());

@@ -30,9 +30,9 @@ def test_compare_results_query_mode(prec):
 
 @pytest.mark.parametrize("pieces", ["1", "3", "8"])
 def test_query_gpu_batch_sent_in_pieces(pieces):
-    """query_gpu on a batch large enough to be sent in pieces (>= 1 MB each): the pieces cross PCIe on a stream of their
-    own while the main stream hashes the ones that have arrived (events between the two); ragged last piece.  A fresh
-    process per setting: ANN_HIP_IO_PIECES is read once."""
+    """query_gpu on a batch large enough to be sent in pieces (>= 1 MB each): the copy kernel of piece i crosses PCIe
+    while the host threads fill piece i+1 of the pinned buffer; one hash launch behind the last piece; ragged last piece.
+    A fresh process per setting: ANN_HIP_IO_PIECES is read once."""
     env = dict(os.environ, ANN_HIP_IO_PIECES=pieces)
     out = subprocess.run([os.path.join(H, "compare_results_f32"), "-n", "20000", "-d", "128", "-y", "16391", "-o", "2", "-S", "43"],
                          capture_output=True, text=True, timeout=600, env=env)
