@@ -612,7 +612,7 @@ static void launch_codes_lpq_d(const QParams &P, size_t Q, const FT *y, u32 *cod
                                size_t smem) {
   if constexpr (DD > 0 && DD * sizeof(FT) <= 512) {
     allow_lds(codes_lpq_kernel<DD>, smem);
-    hipLaunchKernelGGL(codes_lpq_kernel<DD>, grid, dim3(64), smem, s, P, (int)Q, y, codes, zero_me);
+    hipLaunchKernelGGL(codes_lpq_kernel<DD>, grid, dim3(64 * ANN_LPQ_WAVES), smem, s, P, (int)Q, y, codes, zero_me);
   }
 }
 
@@ -632,7 +632,7 @@ static void launch_codes(const QParams &P, size_t Qhash, const FT *y, u32 *codes
   const size_t items = Q * (size_t)P.T;
   if (!items) return;
   if (d_is_fast(P.d) && (size_t)P.d * sizeof(FT) <= 512 && env().codes_lpq) {  // a lane per query (codes_lpq_kernel)
-    const size_t smem = sizeof(FT) * ((size_t)P.ds + 1) * P.d;
+    const size_t smem = sizeof(FT) * ((size_t)P.ds + 1) * P.d + sizeof(u32) * ANN_WAVE * ANN_LPQ_WAVES;
     const dim3 grid((unsigned)((Q + ANN_WAVE - 1) / ANN_WAVE), (unsigned)P.T);
 #define CALL(DD) launch_codes_lpq_d<DD>(P, Q, y, codes, s, zero_me, grid, smem)
     ANN_DISPATCH_D(P.d, CALL);

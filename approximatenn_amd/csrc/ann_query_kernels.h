@@ -207,20 +207,25 @@ __global__ __launch_bounds__(256) void codes_kernel(QParams P, int Q, const FT *
 // row sits in registers (d of them), a projection row comes out of LDS as broadcast reads, and the pairwise tree of
 // compute.cl:160-167 runs literally, in the lane, on d/2 partial sums (level 1 fused with the products; the
 // reference's "+ 0" in every node kept, see row_reduce) -- ~3 d lane instructions per dot and no cross-lane traffic.
-// One 64-lane workgroup = (try, 64 queries).
+// One workgroup = (try, 64 queries); its ANN_LPQ_WAVES waves split the try's ds projections between them (a wave per
+// (try, 64 queries) leaves 1 100 long waves for 1 024 SIMDs at cfg3: the kernel then lasts two wave times).
+#ifndef ANN_LPQ_WAVES
+#define ANN_LPQ_WAVES 2
+#endif
 template <int D>
-__global__ __launch_bounds__(64) void codes_lpq_kernel(QParams P, int Q, const FT *__restrict__ y,
-                                                       u32 *__restrict__ codes, u32 *__restrict__ zero_me) {
+__global__ __launch_bounds__(64 * ANN_LPQ_WAVES) void codes_lpq_kernel(QParams P, int Q, const FT *__restrict__ y,
+                                                                       u32 *__restrict__ codes, u32 *__restrict__ zero_me) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (zero_me && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *zero_me = 0;
   constexpr int NC = D / ANN_VEC;  // 16-byte chunks per row
-  const int lane = lane_id(), t = blockIdx.y;
-  VT *rows = reinterpret_cast<VT *>(smem);  // [ds][NC], then the means [NC]
+  const int lane = lane_id(), t = blockIdx.y, w = threadIdx.x >> 6;
+  VT *rows = reinterpret_cast<VT *>(smem);  // [ds][NC], then the means [NC], then the waves' partial codes
   VT *mean = rows + (size_t)P.ds * NC;
+  u32 *pcode = reinterpret_cast<u32 *>(mean + NC);  // [ANN_LPQ_WAVES][64]
   const VT *src = reinterpret_cast<const VT *>(P.bases + (size_t)t * P.ds * D);
-  for (int i = lane; i < P.ds * NC; i += ANN_WAVE) rows[i] = src[i];
-  for (int i = lane; i < NC; i += ANN_WAVE) mean[i] = reinterpret_cast<const VT *>(P.means)[i];
-  wave_lds_sync();
+  for (int i = threadIdx.x; i < P.ds * NC; i += blockDim.x) rows[i] = src[i];
+  for (int i = threadIdx.x; i < NC; i += blockDim.x) mean[i] = reinterpret_cast<const VT *>(P.means)[i];
+  __syncthreads();
   const int q = blockIdx.x * ANN_WAVE + lane;
   const bool live = q < Q;
   const VT *yp = reinterpret_cast<const VT *>(y + (size_t)(live ? q : Q - 1) * D);
@@ -234,8 +239,9 @@ __global__ __launch_bounds__(64) void codes_lpq_kernel(QParams P, int Q, const F
   }
   const FT zero = 0;
   u32 code = 0;
+  const int sper = (P.ds + ANN_LPQ_WAVES - 1) / ANN_LPQ_WAVES, s_lo = w * sper, s_hi = min(P.ds, s_lo + sper);
 #pragma unroll 1
-  for (int s = 0; s < P.ds; s++) {
+  for (int s = s_lo; s < s_hi; s++) {
     const VT *b = rows + (size_t)s * NC;
     FT m[D / 2];
 #pragma unroll
@@ -257,7 +263,13 @@ __global__ __launch_bounds__(64) void codes_lpq_kernel(QParams P, int Q, const F
     const u32 sign = (u32)(ft_bits(m[0]) >> (sizeof(FT) * 8 - 1));
     code |= sign << (P.ds - 1 - s);  // coord 0 = MSB, compute.cl:223-231
   }
-  if (live) codes[(size_t)q * P.T + t] = code;
+  pcode[w * ANN_WAVE + lane] = code;
+  __syncthreads();
+  if (w == 0 && live) {
+#pragma unroll
+    for (int ww = 1; ww < ANN_LPQ_WAVES; ww++) code |= pcode[ww * ANN_WAVE + lane];
+    codes[(size_t)q * P.T + t] = code;
+  }
 }
 
 // id stored in slot j of query x's candidate row (compute_which, compute.cl:238-246; layout SURVEY Q9).
