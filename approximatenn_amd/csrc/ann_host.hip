@@ -519,11 +519,24 @@ extern "C" void annhip_index_export(const annhip_index *ix, save_t *save) {
 static int layout_code(size_t d, bool allow_oc = true) {
   if (d >= 16 && (d & (d - 1)) == 0 && d <= (sizeof(FT) == 4 ? 1024u : 512u)) return (int)d;
   bool static_oc = false;
+  {  // ANN_HIP_OC_C=c (experiment): the run-time-oc layout with c chunks per lane where d allows it (d = 96: 6 lanes x 4)
+    static const int force_c = env_int("ANN_HIP_OC_C", 0);
+    if (allow_oc && force_c > 0 && d % (ANN_VEC * (size_t)force_c) == 0) {
+      const size_t oc = d / (ANN_VEC * (size_t)force_c);
+      if (oc >= 2 && oc <= 64 && (force_c == 1 || force_c == 2 || force_c == 4 || force_c == 8)) return -force_c;
+    }
+  }
   if (allow_oc && d % ANN_VEC == 0) {
     size_t nc = d / ANN_VEC, C = 1;
     while (C < 8 && nc % (2 * C) == 0) C *= 2;
     const size_t oc = nc / C;
 #ifndef ANN_NO_STATIC_OC
+    // 3 x 8 chunks as 6 lanes x 4 chunks, 5 x 8 as 10 x 4: half the registers per row buffer and twice as long
+    // contiguous pieces per load instruction beat the lanes left idle (12 resp. 10 of the 16 lanes of a DPP row in use):
+    // d = 96 float 40.5 -> 61.1 % of the HBM peak in stage 1, d = 160 51.7 -> 69.0 % (N = 4M, Q = 10k; ANN_HIP_OC6=0: the
+    // 3- and 5-lane forms)
+    static const int oc6 = env_int("ANN_HIP_OC6", 1);
+    if (oc6 && (oc == 3 || oc == 5) && C == 8) return -(int)(16 * (2 * oc) + 4);
     if ((oc == 3 || oc == 5) && C >= 2) return -(int)(16 * oc + C);  // static layout, DPP-only tail (d = 80: oc = 5)
 #endif
     static_oc = C > 2;  // many 16-byte chunks per lane: the aligned layout below beats the fold (d = 384: 4.0 vs 2.4 TB/s)
@@ -580,6 +593,8 @@ static bool layout_is_generic(int code) { return code == 0 || code == ANN_D_FOLD
     case -82: CALL(-82); break;       \
     case -84: CALL(-84); break;       \
     case -88: CALL(-88); break;       \
+    case -100: CALL(-100); break;     \
+    case -164: CALL(-164); break;     \
     case ANN_D_UNALIGNED: CALL(ANN_D_UNALIGNED); break; \
     case ANN_D_FOLD2: CALL(ANN_D_FOLD2); break; \
     case ANN_D_FOLD3: CALL(ANN_D_FOLD3); break; \

@@ -107,6 +107,26 @@ def test_row_lengths_folded_and_neighbours(prec, d):
         save.free()
 
 
+@pytest.mark.parametrize("prec,d", [("f32", 96), ("f32", 160), ("f64", 48), ("f64", 80), ("f32", 24), ("f32", 40), ("f64", 24)])
+def test_row_lengths_static_lane_groups(prec, d):
+    """Row lengths whose 16-byte chunks split as 3 or 5 times a power of two: lane groups of 3, 5 (few chunks per lane)
+    or 6, 10 lanes (3 x 8 and 5 x 8 chunks run as 6 x 4 and 10 x 4: d = 96 / 160 float, 48 / 80 double -- the reference
+    drivers' default row in the stock double build) inside the 16-lane DPP rows, tail of the tree unrolled at compile time.
+    Precomp, query and aliased query against the oracle, bit for bit."""
+    orc, pts, y = _data(prec, 1500, d, 60, 500 + d)
+    orc, (o_ids, o_d, o_save), (ids, dd, save) = _both(prec, pts, y, 7, 4)
+    try:
+        assert np.array_equal(ids, o_ids) and bits_equal(dd, o_d)
+        assert_save_equal(save.to_dict(), o_save)
+        want, got = orc.query(o_save, pts, y), A.query(save, pts, y)
+        assert np.array_equal(got[0], want[0]) and bits_equal(got[1], want[1])
+        want, got = orc.query(o_save, pts, 300, alias=True), A.query(save, pts, pts[:300])
+        assert np.array_equal(got[0], want[0]) and bits_equal(got[1], want[1])
+    finally:
+        A._lib.load(prec).annhip_cache_clear()
+        save.free()
+
+
 @pytest.mark.parametrize("d", [16, 512, 1024, 48, 130])
 def test_row_lengths_fast_and_generic(d):
     """smallest / largest register-tiled d, and two generic (non power of two) ones; float."""
