@@ -538,6 +538,7 @@ static int layout_code(size_t d, bool allow_oc = true) {
     static const int oc6 = env_int("ANN_HIP_OC6", 1);
     if (oc6 && (oc == 3 || oc == 5) && C == 8) return -(int)(16 * (2 * oc) + 4);
     if ((oc == 3 || oc == 5) && C >= 2) return -(int)(16 * oc + C);  // static layout, DPP-only tail (d = 80: oc = 5)
+    if (oc6 && (oc == 6 || oc == 10) && C == 8) return -(int)(16 * oc + C);  // 3 x 16 / 5 x 16 chunks: d = 192 / 320 float
 #endif
     static_oc = C > 2;  // many 16-byte chunks per lane: the aligned layout below beats the fold (d = 384: 4.0 vs 2.4 TB/s)
   }
@@ -594,7 +595,9 @@ static bool layout_is_generic(int code) { return code == 0 || code == ANN_D_FOLD
     case -84: CALL(-84); break;       \
     case -88: CALL(-88); break;       \
     case -100: CALL(-100); break;     \
+    case -104: CALL(-104); break;     \
     case -164: CALL(-164); break;     \
+    case -168: CALL(-168); break;     \
     case ANN_D_UNALIGNED: CALL(ANN_D_UNALIGNED); break; \
     case ANN_D_FOLD2: CALL(ANN_D_FOLD2); break; \
     case ANN_D_FOLD3: CALL(ANN_D_FOLD3); break; \

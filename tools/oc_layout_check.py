@@ -2,7 +2,7 @@ import sys, os, numpy as np
 sys.path.insert(0, os.getcwd())
 import approximatenn_amd as A
 from oracle import oracle_py as O
-for d in (96, 160, 48):
+for d in [int(v) for v in os.environ.get("OC_DIMS", "96,160,48").split(",")]:
     n, Q, k, T = 5000, 300, 10, 5
     orc = O.CpuBackend("f32", "oracle")
     O.srandom(5 + d); orc.rand_norm_reset()
