@@ -538,7 +538,7 @@ static int layout_code(size_t d, bool allow_oc = true) {
     static const int oc6 = env_int("ANN_HIP_OC6", 1);
     if (oc6 && (oc == 3 || oc == 5) && C == 8) return -(int)(16 * (2 * oc) + 4);
     if ((oc == 3 || oc == 5) && C >= 2) return -(int)(16 * oc + C);  // static layout, DPP-only tail (d = 80: oc = 5)
-    if (oc6 && (oc == 6 || oc == 10) && C == 8) return -(int)(16 * oc + C);  // 3 x 16 / 5 x 16 chunks: d = 192 / 320 float
+    if (oc6 && (oc == 6 || oc == 10 || oc == 12) && C == 8) return -(int)(16 * oc + C);  // 3 x 16 / 5 x 16 / 3 x 32 chunks: d = 192 / 320 / 384 float
 #endif
     static_oc = C > 2;  // many 16-byte chunks per lane: the aligned layout below beats the fold (d = 384: 4.0 vs 2.4 TB/s)
   }
@@ -598,6 +598,7 @@ static bool layout_is_generic(int code) { return code == 0 || code == ANN_D_FOLD
     case -104: CALL(-104); break;     \
     case -164: CALL(-164); break;     \
     case -168: CALL(-168); break;     \
+    case -200: CALL(-200); break;     \
     case ANN_D_UNALIGNED: CALL(ANN_D_UNALIGNED); break; \
     case ANN_D_FOLD2: CALL(ANN_D_FOLD2); break; \
     case ANN_D_FOLD3: CALL(ANN_D_FOLD3); break; \

@@ -108,12 +108,12 @@ def test_row_lengths_folded_and_neighbours(prec, d):
 
 
 @pytest.mark.parametrize("prec,d", [("f32", 96), ("f32", 160), ("f64", 48), ("f64", 80), ("f32", 24), ("f32", 40), ("f64", 24),
-                                    ("f32", 192), ("f32", 320), ("f64", 96), ("f64", 160)])
+                                    ("f32", 192), ("f32", 320), ("f64", 96), ("f64", 160), ("f32", 384), ("f64", 192)])
 def test_row_lengths_static_lane_groups(prec, d):
     """Row lengths whose 16-byte chunks split as 3 or 5 times a power of two: lane groups of 3, 5 (few chunks per lane)
     or 6, 10 lanes (3 x 8 and 5 x 8 chunks run as 6 x 4 and 10 x 4: d = 96 / 160 float, 48 / 80 double -- the reference
     drivers' default row in the stock double build; 3 x 16 and 5 x 16 chunks as 6 x 8 and 10 x 8: d = 192 / 320 float,
-    96 / 160 double) inside the 16-lane DPP rows, tail of the tree unrolled at compile time.
+    96 / 160 double; 3 x 32 chunks as 12 x 8: d = 384 float, 192 double) inside the 16-lane DPP rows, tail of the tree unrolled at compile time.
     Precomp, query and aliased query against the oracle, bit for bit."""
     orc, pts, y = _data(prec, 1500, d, 60, 500 + d)
     orc, (o_ids, o_d, o_save), (ids, dd, save) = _both(prec, pts, y, 7, 4)
