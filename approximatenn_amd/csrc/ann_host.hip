@@ -536,6 +536,7 @@ static int layout_code(size_t d, bool allow_oc = true) {
     // d = 96 float 40.5 -> 61.1 % of the HBM peak in stage 1, d = 160 51.7 -> 69.0 % (N = 4M, Q = 10k; ANN_HIP_OC6=0: the
     // 3- and 5-lane forms)
     static const int oc6 = env_int("ANN_HIP_OC6", 1);
+    // (5 x 4 chunks as 10 x 2 -- d = 80 float -- was measured too and loses: 52.2 % against 68.7 %)
     if (oc6 && (oc == 3 || oc == 5) && C == 8) return -(int)(16 * (2 * oc) + 4);
     if ((oc == 3 || oc == 5) && C >= 2) return -(int)(16 * oc + C);  // static layout, DPP-only tail (d = 80: oc = 5)
     if (oc6 && (oc == 6 || oc == 10 || oc == 12) && C == 8) return -(int)(16 * oc + C);  // 3 x 16 / 5 x 16 / 3 x 32 chunks: d = 192 / 320 / 384 float
